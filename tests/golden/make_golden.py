@@ -1,0 +1,134 @@
+"""Generate the golden vectors in this directory by running THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference, which never travels to the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference modules gpnerf/{projection,render_ray,render_image,transformer_network}.py are
+imported unmodified from /root/reference and run on CPU (torch CPU fp32, eval mode, det=True) on
+seeded synthetic inputs built by gp_nerf_amd.synth (counter-based hash -> bit-identical anywhere).
+Only OUTPUTS are stored (plus a SHA-256 of the regenerated inputs); tests rebuild the inputs from
+the same seeds via `cases.py`.  The semantic head is not covered: its reference module needs
+detectron2/fvcore (absent) -> parity unpinned (see oracle/sem_head.py).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+from gpnerf.projection import Projector  # noqa: E402  (reference)
+from gpnerf.render_image import render_single_image  # noqa: E402  (reference)
+from gpnerf.render_ray import (raw2outputs, render_rays, sample_along_camera_ray,  # noqa: E402
+                               sample_fine_pts)
+from gpnerf.transformer_network import GNT  # noqa: E402  (reference)
+
+sys.path.insert(0, HERE)
+import cases  # noqa: E402
+
+
+def ref_gnt(sd):
+    args = types.SimpleNamespace(netwidth=64, trans_depth=8, save_feature=False,
+                                 semantic_model="fpn", num_classes=20)
+    net = GNT(args, in_feat_ch=32, posenc_dim=63, viewenc_dim=63, ret_alpha=True)
+    net.load_state_dict(sd, strict=True)
+    return net.eval()
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
+
+
+@torch.no_grad()
+def main():
+    torch.manual_seed(0)
+    proj = Projector("cpu")
+
+    # ---- G1 projector
+    c = cases.g1_projector()
+    rgb_feat, deep, ray_diff, mask = proj.compute(c["pts"], c["camera"], c["src_rgbs"],
+                                                  c["src_cameras"], c["featmaps"],
+                                                  c["deep_semantics"])
+    pix, in_front = proj.compute_projections(c["pts"], c["src_cameras"][0])
+    save("g1_projector", sha=cases.sha(c), pix=np_(pix), in_front=np_(in_front),
+         rgb_feat=np_(rgb_feat), ray_diff=np_(ray_diff), mask=np_(mask),
+         deep_head=np_(deep[:8]), deep_sum=np_(deep.double().sum(dim=-1)))
+
+    # ---- G2 GNT
+    sd = cases.weights()
+    net = ref_gnt(sd)
+    for S in (48, 64):
+        c = cases.g2_gnt(S)
+        out, sem, sem3d = net(c["rgb_feat"], c["deep_sem"], c["ray_diff"], c["mask"], c["pts"],
+                              c["ray_d"])
+        extra = dict(sem3d=np_(sem3d)) if S == 48 else dict(sem3d_sum=np_(sem3d.double().sum(-1)))
+        save("g2_gnt_s%d" % S, sha=cases.sha(c), out=np_(out), sem=np_(sem), **extra)
+
+    # ---- G3 samplers
+    c = cases.g3_samplers()
+    arrays = {}
+    for inv in (False, True):
+        pts, z = sample_along_camera_ray(c["ray_o"], c["ray_d"], c["depth_range"], 48,
+                                         inv_uniform=inv, det=True)
+        fpts, fz = sample_fine_pts(inv, 16, True, 48, c, c["weights"].clone(), z)
+        tag = "inv" if inv else "lin"
+        arrays.update({"pts_" + tag: np_(pts), "z_" + tag: np_(z), "fpts_" + tag: np_(fpts),
+                       "fz_" + tag: np_(fz)})
+    r2o = raw2outputs(c["raw"], arrays_z := torch.from_numpy(arrays["z_lin"]), c["vis_mask"])
+    arrays.update({"r2o_" + k: np_(v) for k, v in r2o.items()})
+    r2o_w = raw2outputs(c["raw"], arrays_z, c["vis_mask"], white_bkgd=True)
+    arrays["r2o_rgb_white"] = np_(r2o_w["rgb"])
+    save("g3_samplers", sha=cases.sha(c), **arrays)
+
+    # ---- G4 render_rays (two-pass, C1-shaped, reduced)
+    c = cases.g4_render_rays()
+    model = types.SimpleNamespace(net_coarse=net, net_fine=None)
+    ret = render_rays(c["ray_batch"], model, c["featmaps"], c["deep_semantics"], proj,
+                      N_samples=48, inv_uniform=True, N_importance=16, det=True, ret_alpha=True,
+                      single_net=True)
+    arrays = {}
+    for lvl in ("outputs_coarse", "outputs_fine"):
+        o = ret[lvl]
+        t = lvl.split("_")[1]
+        arrays.update({t + "_rgb": np_(o["rgb"]), t + "_weights": np_(o["weights"]),
+                       t + "_depth": np_(o["depth"]), t + "_feats_out": np_(o["feats_out"]),
+                       t + "_f3d_head": np_(o["feats_out_3d"][:4]),
+                       t + "_f3d_sum": np_(o["feats_out_3d"].double().sum(-1))})
+    save("g4_render_rays", sha=cases.sha(c), **arrays)
+
+    # ---- G5 render_single_image, two chunk sizes must agree
+    c = cases.g5_render_image()
+    sampler = types.SimpleNamespace(H=c["H"], W=c["W"])
+    outs = []
+    for chunk in (50, 768):
+        r = render_single_image(sampler, c["ray_batch"], model, proj, chunk, N_samples=16,
+                                inv_uniform=True, N_importance=8, det=True, render_stride=1,
+                                featmaps=c["featmaps"], deep_semantics=c["deep_semantics"],
+                                ret_alpha=True, single_net=True)
+        outs.append(r)
+    arrays = {}
+    for lvl in ("outputs_coarse", "outputs_fine"):
+        t = lvl.split("_")[1]
+        a, b = outs[0][lvl], outs[1][lvl]
+        for k in ("rgb", "depth", "weights", "feats_out"):
+            arrays[t + "_" + k] = np_(b[k])
+            arrays[t + "_" + k + "_chunkdiff"] = np.float64((a[k] - b[k]).abs().max().item())
+        arrays[t + "_f3d_shape"] = np.array(b["feats_out_3d"].shape)
+        arrays[t + "_f3d_sum"] = np_(b["feats_out_3d"].double().reshape(c["H"], c["W"], -1, 512).sum(-1))
+    save("g5_render_image", sha=cases.sha(c), **arrays)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,24 @@
+// Shared host-side helpers for libgpnerf_hip.so (error text, argument checks, launch checks).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/gpnerf_hip.h"
+
+int gpn_set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define GPN_REQUIRE(cond, ...)                                  \
+  do {                                                          \
+    if (!(cond)) return gpn_set_error(GPN_E_ARG, __VA_ARGS__);  \
+  } while (0)
+
+#define GPN_LAUNCH_CHECK(name)                                                          \
+  do {                                                                                  \
+    hipError_t e_ = hipGetLastError();                                                  \
+    if (e_ != hipSuccess)                                                               \
+      return gpn_set_error(GPN_E_LAUNCH, "%s: %s", (name), hipGetErrorString(e_));      \
+  } while (0)
+
+static inline int gpn_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Number of compute units of the current device (cached); grids of persistent kernels scale with it.
+int gpn_num_cus();

@@ -1,0 +1,952 @@
+// GNT forward (north_star subsystem 2) on fp32 MFMA: reference gpnerf/transformer_network.py.
+// One kernel per stage; every stage keeps its activations in registers in the transposed "T-tile"
+// layout of gnt_mfma.h (16 points per wave-tile), weights staged once per workgroup into LDS,
+// workgroups persistent over tiles.  Stages:
+//   k_posenc      Embedder x2                                   (:6-37, :297-306)
+//   k_rgbfeat     rgbfeat_fc + max over views                   (:309-311)
+//   k_view_attn   attn_norm + Attention2D + residual            (:74-88, :107-112)
+//   k_ff          x + FeedForward(LayerNorm(x))                 (:40-51, :114-117, :210-213)
+//   k_qpos        q_fcs[i] on cat(q, posenc, viewenc)           (:322-324)
+//   k_ray_attn    attn_norm + Attention('qk') + residual        (:149-178, :203-208)
+//   k_sem         deep-semantic aggregation, fused over layers  (:90, :180-184, :335-336)
+//   k_heads_rgb / k_sem_adaptor   output heads                  (:332-338)
+#include "common.h"
+#include "gnt_mfma.h"
+#include "proj_common.h"
+
+#define C64 64
+#define LDW 68  // padded leading dimension of a 64-wide weight matrix in LDS
+
+extern __shared__ __attribute__((aligned(16))) float smem[];
+
+static int set_lds_limit(const void* fn, size_t bytes) {
+  if (bytes <= 64 * 1024) return GPN_OK;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess)
+    return gpn_set_error(GPN_E_LAUNCH, "hipFuncSetAttribute(%zu B LDS): %s", bytes,
+                         hipGetErrorString(e));
+  return GPN_OK;
+}
+
+static int persistent_grid(long long work_items) {
+  const long long cus = gpn_num_cus();
+  return (int)(work_items < cus ? (work_items < 1 ? 1 : work_items) : cus);
+}
+
+// ------------------------------------------------------------------------------------ posenc
+__global__ void k_posenc(const float* __restrict__ pts, const float* __restrict__ ray_d, int S,
+                         long long N, float* __restrict__ emb) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * GPN_EMB) return;
+  const long long n = idx >> 7;
+  const int c = (int)(idx & 127);
+  float val = 0.0f;
+  if (c < 126) {
+    float sx, sy, sz;
+    int k;
+    if (c < 63) {
+      sx = pts[n * 3 + 0], sy = pts[n * 3 + 1], sz = pts[n * 3 + 2];
+      k = c;
+    } else {
+      const long long r = n / S;
+      const float dx = ray_d[r * 3 + 0], dy = ray_d[r * 3 + 1], dz = ray_d[r * 3 + 2];
+      const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+      sx = dx / nrm, sy = dy / nrm, sz = dz / nrm;
+      k = c - 63;
+    }
+    if (k < 3) {
+      val = k == 0 ? sx : (k == 1 ? sy : sz);
+    } else {
+      const int k3 = k - 3, f = k3 / 6, rem = k3 - 6 * f, comp = rem % 3;
+      const float arg = (comp == 0 ? sx : (comp == 1 ? sy : sz)) * (float)(1 << f);
+      val = rem >= 3 ? cosf(arg) : sinf(arg);
+    }
+  }
+  emb[idx] = val;
+}
+
+// ------------------------------------------------------------------------------------ rgbfeat
+// LDS: W0 [64][52] (in_ch zero-padded to 48), W2 [64][68], b0 [64], b2 [64]
+#define RF_LD0 52
+__global__ void __launch_bounds__(512)
+k_rgbfeat(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ rgb_feat, long long N, int V,
+          int in_ch, float* __restrict__ feat, float* __restrict__ q0) {
+  float* W0 = smem;
+  float* W2 = W0 + 64 * RF_LD0;
+  float* b0 = W2 + 64 * LDW;
+  float* b2 = b0 + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  stage_padded(W0, RF_LD0, 64, 48, fc0.w, 64, in_ch, tid, 512);
+  stage_matrix(W2, LDW, fc2.w, 64, 64, tid, 512);
+  stage_vector(b0, 64, fc0.b, 64, tid, 512);
+  stage_vector(b2, 64, fc2.b, 64, tid, 512);
+  __syncthreads();
+  const int j = lane & 15, g = lane >> 4;
+  const long long ntiles = (N + 15) >> 4;
+  for (long long tile = (long long)blockIdx.x * 8 + wave; tile < ntiles;
+       tile += (long long)gridDim.x * 8) {
+    const long long n = tile * 16 + j;
+    const bool valid = n < N;
+    const long long nc = valid ? n : N - 1;
+    f4 qmax[4];
+#pragma unroll
+    for (int M = 0; M < 4; ++M) qmax[M] = f4_splat(-INFINITY);
+    for (int v = 0; v < V; ++v) {
+      const float* row = rgb_feat + ((size_t)nc * V + v) * in_ch;
+      f4 x[3];
+#pragma unroll
+      for (int T = 0; T < 3; ++T)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * T + 4 * g + r;
+          x[T][r] = c < in_ch ? row[c] : 0.0f;
+        }
+      f4 h[4], y[4];
+#pragma unroll
+      for (int M = 0; M < 4; ++M) h[M] = ld4(b0 + 16 * M + 4 * g);
+      lin_T<3, 4>(W0, RF_LD0, x, h, lane);
+#pragma unroll
+      for (int M = 0; M < 4; ++M) {
+        h[M] = f4_relu(h[M]);
+        y[M] = ld4(b2 + 16 * M + 4 * g);
+      }
+      lin_T<4, 4>(W2, LDW, h, y, lane);
+      float* out = feat + ((size_t)nc * V + v) * C64 + 4 * g;
+#pragma unroll
+      for (int M = 0; M < 4; ++M) {
+        if (valid) st4(out + 16 * M, y[M]);
+        qmax[M] = f4_max(qmax[M], y[M]);
+      }
+    }
+    if (valid) {
+#pragma unroll
+      for (int M = 0; M < 4; ++M) st4(q0 + (size_t)n * C64 + 16 * M + 4 * g, qmax[M]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ view attention
+// LDS image (floats):
+//   Wq, Wk, Wv, Wo [64][68] | pos2 [64][20] | attn0 [16][68] | attn2 [64][20] | pos0 [16][4]
+//   | b_pos0[16] b_pos2[64] b_attn0[16] b_attn2[64] b_out[64] gamma[64] beta[64]
+#define VA_LD8 20
+struct ViewLds {
+  float *Wq, *Wk, *Wv, *Wo, *P2, *A0, *A2, *P0, *bP0, *bP2, *bA0, *bA2, *bO, *gam, *bet;
+};
+__device__ __forceinline__ ViewLds view_lds(float* s) {
+  ViewLds L;
+  L.Wq = s;
+  L.Wk = L.Wq + 64 * LDW;
+  L.Wv = L.Wk + 64 * LDW;
+  L.Wo = L.Wv + 64 * LDW;
+  L.P2 = L.Wo + 64 * LDW;
+  L.A0 = L.P2 + 64 * VA_LD8;
+  L.A2 = L.A0 + 16 * LDW;
+  L.P0 = L.A2 + 64 * VA_LD8;
+  L.bP0 = L.P0 + 64;
+  L.bP2 = L.bP0 + 16;
+  L.bA0 = L.bP2 + 64;
+  L.bA2 = L.bA0 + 16;
+  L.bO = L.bA2 + 64;
+  L.gam = L.bO + 64;
+  L.bet = L.gam + 64;
+  return L;
+}
+constexpr int VIEW_LDS_FLOATS = 4 * 64 * LDW + 2 * 64 * VA_LD8 + 16 * LDW + 64 + 16 + 64 + 16 + 64 * 4;
+
+__global__ void __launch_bounds__(512)
+k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __restrict__ feat,
+            const float* __restrict__ ray_diff, const float* __restrict__ mask, long long N, int V,
+            float* __restrict__ q_out, float* __restrict__ logits, float* __restrict__ stats) {
+  const ViewLds L = view_lds(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  stage_matrix(L.Wq, LDW, Lw.q.w, 64, 64, tid, 512);
+  stage_matrix(L.Wk, LDW, Lw.k.w, 64, 64, tid, 512);
+  stage_matrix(L.Wv, LDW, Lw.v.w, 64, 64, tid, 512);
+  stage_matrix(L.Wo, LDW, Lw.out.w, 64, 64, tid, 512);
+  stage_padded(L.P2, VA_LD8, 64, 16, Lw.pos2.w, 64, 8, tid, 512);
+  stage_padded(L.A0, LDW, 16, 64, Lw.attn0.w, 8, 64, tid, 512);
+  stage_padded(L.A2, VA_LD8, 64, 16, Lw.attn2.w, 64, 8, tid, 512);
+  stage_padded(L.P0, 4, 16, 4, Lw.pos0.w, 8, 4, tid, 512);
+  stage_vector(L.bP0, 16, Lw.pos0.b, 8, tid, 512);
+  stage_vector(L.bP2, 64, Lw.pos2.b, 64, tid, 512);
+  stage_vector(L.bA0, 16, Lw.attn0.b, 8, tid, 512);
+  stage_vector(L.bA2, 64, Lw.attn2.b, 64, tid, 512);
+  stage_vector(L.bO, 64, Lw.out.b, 64, tid, 512);
+  stage_vector(L.gam, 64, Lw.attn_norm_w, 64, tid, 512);
+  stage_vector(L.bet, 64, Lw.attn_norm_b, 64, tid, 512);
+  __syncthreads();
+
+  const int j = lane & 15, g = lane >> 4;
+  const float p0w = L.P0[j * 4 + g];  // A operand of the 4 -> 8 layer: W[i = j][k = g]
+  const long long ntiles = (N + 15) >> 4;
+  for (long long tile = (long long)blockIdx.x * 8 + wave; tile < ntiles;
+       tile += (long long)gridDim.x * 8) {
+    const long long n = tile * 16 + j;
+    const bool valid = n < N;
+    const long long nc = valid ? n : N - 1;
+
+    f4 xq[4], qp[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) xq[T] = ld4(q_in + (size_t)nc * C64 + 16 * T + 4 * g);
+    {
+      f4 qn[4];
+      layernorm_T(xq, qn, L.gam, L.bet, 1e-6f, lane);
+#pragma unroll
+      for (int M = 0; M < 4; ++M) qp[M] = f4_zero();
+      lin_T<4, 4>(L.Wq, LDW, qn, qp, lane);
+    }
+    f4 mrun[4], lrun[4], acc[4];
+#pragma unroll
+    for (int M = 0; M < 4; ++M) {
+      mrun[M] = f4_splat(-INFINITY);
+      lrun[M] = f4_zero();
+      acc[M] = f4_zero();
+    }
+    const float* frow = feat + (size_t)nc * V * C64 + 4 * g;
+    f4 fcur[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) fcur[T] = ld4(frow + 16 * T);
+
+    for (int v = 0; v < V; ++v) {
+      f4 fnext[4];
+      const int vn = v + 1 < V ? v + 1 : v;
+#pragma unroll
+      for (int T = 0; T < 4; ++T) fnext[T] = ld4(frow + (size_t)vn * C64 + 16 * T);
+      const float rd = ray_diff[((size_t)nc * V + v) * 4 + g];
+      const float mk = mask[(size_t)nc * V + v];
+
+      f4 k[4], val[4];
+#pragma unroll
+      for (int M = 0; M < 4; ++M) k[M] = f4_zero(), val[M] = f4_zero();
+      lin_T<4, 4>(L.Wk, LDW, fcur, k, lane);   // k = k_fc(feat)
+      lin_T<4, 4>(L.Wv, LDW, k, val, lane);    // v = v_fc(k)   (reference quirk, :77)
+      // pos = pos_fc(ray_diff): 4 -> 8 (ReLU) -> 64
+      f4 ph = mfma16(p0w, rd, ld4(L.bP0 + 4 * g));
+      ph = f4_relu(ph);
+      f4 pos[4];
+#pragma unroll
+      for (int M = 0; M < 4; ++M) pos[M] = ld4(L.bP2 + 16 * M + 4 * g);
+      lin_T<1, 4>(L.P2, VA_LD8, &ph, pos, lane);
+      // attn = attn_fc(k - q + pos): 64 -> 8 (ReLU) -> 64
+      f4 ain[4];
+#pragma unroll
+      for (int M = 0; M < 4; ++M) ain[M] = k[M] - qp[M] + pos[M];
+      f4 ah = ld4(L.bA0 + 4 * g);
+      lin_T<4, 1>(L.A0, LDW, ain, &ah, lane);
+      ah = f4_relu(ah);
+      f4 a[4];
+#pragma unroll
+      for (int M = 0; M < 4; ++M) a[M] = ld4(L.bA2 + 16 * M + 4 * g);
+      lin_T<1, 4>(L.A2, VA_LD8, &ah, a, lane);
+      if (mk == 0.0f) {
+#pragma unroll
+        for (int M = 0; M < 4; ++M) a[M] = f4_splat(-1e9f);  // masked_fill (:83)
+      }
+      if (logits != nullptr && valid) {
+        float* lo = logits + ((size_t)n * V + v) * C64 + 4 * g;
+#pragma unroll
+        for (int M = 0; M < 4; ++M) st4(lo + 16 * M, a[M]);
+      }
+      // online softmax over views, per channel (:84-87)
+#pragma unroll
+      for (int M = 0; M < 4; ++M)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float mn = fmaxf(mrun[M][r], a[M][r]);
+          const float alpha = __expf(mrun[M][r] - mn);
+          const float p = __expf(a[M][r] - mn);
+          lrun[M][r] = lrun[M][r] * alpha + p;
+          acc[M][r] = acc[M][r] * alpha + (val[M][r] + pos[M][r]) * p;
+          mrun[M][r] = mn;
+        }
+#pragma unroll
+      for (int T = 0; T < 4; ++T) fcur[T] = fnext[T];
+    }
+    f4 xs[4], y[4], rl[4];
+#pragma unroll
+    for (int M = 0; M < 4; ++M) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rl[M][r] = 1.0f / lrun[M][r];
+      xs[M] = acc[M] * rl[M];
+      y[M] = ld4(L.bO + 16 * M + 4 * g);
+    }
+    lin_T<4, 4>(L.Wo, LDW, xs, y, lane);
+    if (valid) {
+#pragma unroll
+      for (int M = 0; M < 4; ++M) st4(q_out + (size_t)n * C64 + 16 * M + 4 * g, y[M] + xq[M]);
+      if (stats != nullptr) {
+#pragma unroll
+        for (int M = 0; M < 4; ++M) {
+          st4(stats + (size_t)n * 128 + 16 * M + 4 * g, mrun[M]);
+          st4(stats + (size_t)n * 128 + 64 + 16 * M + 4 * g, rl[M]);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ feed-forward
+// LDS: W1 [256][68] | W2 [64][260] | b1 [256] | b2 [64] | gamma [64] | beta [64]
+#define FF_LD2 260
+constexpr int FF_LDS_FLOATS = 256 * LDW + 64 * FF_LD2 + 256 + 64 * 3;
+
+__global__ void __launch_bounds__(512)
+k_ff(const float* __restrict__ norm_w, const float* __restrict__ norm_b, gpn_linear_t fc1,
+     gpn_linear_t fc2, const float* __restrict__ x_in, long long N, float* __restrict__ x_out) {
+  float* W1 = smem;
+  float* W2 = W1 + 256 * LDW;
+  float* b1 = W2 + 64 * FF_LD2;
+  float* b2 = b1 + 256;
+  float* gam = b2 + 64;
+  float* bet = gam + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  stage_matrix(W1, LDW, fc1.w, 256, 64, tid, 512);
+  stage_matrix(W2, FF_LD2, fc2.w, 64, 256, tid, 512);
+  stage_vector(b1, 256, fc1.b, 256, tid, 512);
+  stage_vector(b2, 64, fc2.b, 64, tid, 512);
+  stage_vector(gam, 64, norm_w, 64, tid, 512);
+  stage_vector(bet, 64, norm_b, 64, tid, 512);
+  __syncthreads();
+  const int j = lane & 15, g = lane >> 4;
+  const long long ntiles = (N + 15) >> 4;
+  for (long long tile = (long long)blockIdx.x * 8 + wave; tile < ntiles;
+       tile += (long long)gridDim.x * 8) {
+    const long long n = tile * 16 + j;
+    const bool valid = n < N;
+    const long long nc = valid ? n : N - 1;
+    f4 x[4], xn[4], h[16], y[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) x[T] = ld4(x_in + (size_t)nc * C64 + 16 * T + 4 * g);
+    layernorm_T(x, xn, gam, bet, 1e-6f, lane);
+#pragma unroll
+    for (int M = 0; M < 16; ++M) h[M] = ld4(b1 + 16 * M + 4 * g);
+    lin_T<4, 16>(W1, LDW, xn, h, lane);
+#pragma unroll
+    for (int M = 0; M < 16; ++M) h[M] = f4_relu(h[M]);
+#pragma unroll
+    for (int M = 0; M < 4; ++M) y[M] = ld4(b2 + 16 * M + 4 * g);
+    lin_T<16, 4>(W2, FF_LD2, h, y, lane);
+    if (valid) {
+#pragma unroll
+      for (int M = 0; M < 4; ++M) st4(x_out + (size_t)n * C64 + 16 * M + 4 * g, y[M] + x[M]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ q positional MLP
+// input = [q (64) | emb (126 + 2 zero pad)] = 192 channels; LDS: W0 [64][196] | W2 [64][68] | b0 | b2
+#define QP_LD0 196
+constexpr int QP_LDS_FLOATS = 64 * QP_LD0 + 64 * LDW + 128;
+
+__global__ void __launch_bounds__(512)
+k_qpos(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ q_in,
+       const float* __restrict__ emb, long long N, float* __restrict__ q_out) {
+  float* W0 = smem;
+  float* W2 = W0 + 64 * QP_LD0;
+  float* b0 = W2 + 64 * LDW;
+  float* b2 = b0 + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  stage_padded(W0, QP_LD0, 64, 192, fc0.w, 64, 190, tid, 512);
+  stage_matrix(W2, LDW, fc2.w, 64, 64, tid, 512);
+  stage_vector(b0, 64, fc0.b, 64, tid, 512);
+  stage_vector(b2, 64, fc2.b, 64, tid, 512);
+  __syncthreads();
+  const int j = lane & 15, g = lane >> 4;
+  const long long ntiles = (N + 15) >> 4;
+  for (long long tile = (long long)blockIdx.x * 8 + wave; tile < ntiles;
+       tile += (long long)gridDim.x * 8) {
+    const long long n = tile * 16 + j;
+    const bool valid = n < N;
+    const long long nc = valid ? n : N - 1;
+    f4 x[12], h[4], y[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) x[T] = ld4(q_in + (size_t)nc * C64 + 16 * T + 4 * g);
+#pragma unroll
+    for (int T = 0; T < 8; ++T) x[4 + T] = ld4(emb + (size_t)nc * GPN_EMB + 16 * T + 4 * g);
+#pragma unroll
+    for (int M = 0; M < 4; ++M) h[M] = ld4(b0 + 16 * M + 4 * g);
+    lin_T<12, 4>(W0, QP_LD0, x, h, lane);
+#pragma unroll
+    for (int M = 0; M < 4; ++M) {
+      h[M] = f4_relu(h[M]);
+      y[M] = ld4(b2 + 16 * M + 4 * g);
+    }
+    lin_T<4, 4>(W2, LDW, h, y, lane);
+    if (valid) {
+#pragma unroll
+      for (int M = 0; M < 4; ++M) st4(q_out + (size_t)n * C64 + 16 * M + 4 * g, y[M]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ ray attention
+// One wave per 16-sample tile of a ray; RPW rays per workgroup share the weights.
+// LDS: Wq Wk Wv Wo [64][68] | bO gamma beta [64] | Ks [RPW][S][68] | Vt [RPW][64][S+4]
+//      | part [RPW][NT][4][S]   (per-wave column sums of A, reduced in fixed order)
+template <int NT>
+struct RayCfg {
+  static constexpr int RPW = NT <= 4 ? 2 : 1;
+  static constexpr int S = NT * 16;
+  static constexpr int LDV = S + 4;
+  static constexpr int THREADS = RPW * NT * 64;
+  static constexpr int LDS_FLOATS =
+      4 * 64 * LDW + 3 * 64 + RPW * S * LDW + RPW * 64 * LDV + RPW * NT * 4 * S;
+};
+
+template <int NT>
+__global__ void __launch_bounds__(RayCfg<NT>::THREADS)
+k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, float* __restrict__ x_out,
+           float* __restrict__ abar, float* __restrict__ weights) {
+  using Cfg = RayCfg<NT>;
+  constexpr int S = Cfg::S, RPW = Cfg::RPW, LDV = Cfg::LDV, NTHR = Cfg::THREADS;
+  float* Wq = smem;
+  float* Wk = Wq + 64 * LDW;
+  float* Wv = Wk + 64 * LDW;
+  float* Wo = Wv + 64 * LDW;
+  float* bO = Wo + 64 * LDW;
+  float* gam = bO + 64;
+  float* bet = gam + 64;
+  float* Ks = bet + 64;
+  float* Vt = Ks + RPW * S * LDW;
+  float* part = Vt + RPW * 64 * LDV;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  stage_matrix(Wq, LDW, Lw.q.w, 64, 64, tid, NTHR);
+  stage_matrix(Wk, LDW, Lw.k.w, 64, 64, tid, NTHR);
+  stage_matrix(Wv, LDW, Lw.v.w, 64, 64, tid, NTHR);
+  stage_matrix(Wo, LDW, Lw.out.w, 64, 64, tid, NTHR);
+  stage_vector(bO, 64, Lw.out.b, 64, tid, NTHR);
+  stage_vector(gam, 64, Lw.attn_norm_w, 64, tid, NTHR);
+  stage_vector(bet, 64, Lw.attn_norm_b, 64, tid, NTHR);
+  __syncthreads();
+  const int j = lane & 15, g = lane >> 4;
+  const int slot = wave / NT, t = wave - slot * NT;
+  float* Ks_s = Ks + slot * S * LDW;
+  float* Vt_s = Vt + slot * 64 * LDV;
+
+  for (int grp = blockIdx.x; grp * RPW < R; grp += gridDim.x) {
+    const int ray = grp * RPW + slot;
+    const bool valid = ray < R;
+    const int rc = valid ? ray : R - 1;
+    const size_t row = ((size_t)rc * S + 16 * t + j) * C64;
+    f4 x[4], xn[4], qT[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) x[T] = ld4(x_in + row + 16 * T + 4 * g);
+    layernorm_T(x, xn, gam, bet, 1e-6f, lane);
+#pragma unroll
+    for (int M = 0; M < 4; ++M) qT[M] = f4_zero();
+    lin_T<4, 4>(Wq, LDW, xn, qT, lane);
+    {
+      f4 kT[4];
+#pragma unroll
+      for (int M = 0; M < 4; ++M) kT[M] = f4_zero();
+      lin_T<4, 4>(Wk, LDW, xn, kT, lane);
+#pragma unroll
+      for (int M = 0; M < 4; ++M) st4(Ks_s + (16 * t + j) * LDW + 16 * M + 4 * g, kT[M]);
+    }
+    {
+      f4 vT[4];
+#pragma unroll
+      for (int M = 0; M < 4; ++M) vT[M] = f4_zero();
+      lin_T<4, 4>(Wv, LDW, xn, vT, lane);
+#pragma unroll
+      for (int M = 0; M < 4; ++M)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Vt_s[(16 * M + 4 * g + r) * LDV + 16 * t + j] = vT[M][r];
+    }
+    __syncthreads();
+
+    f4 oT[4], wacc[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) wacc[kt] = f4_zero();
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      // S^T tile: rows = keys, columns (lanes) = this wave's 16 queries; k-dim = the head's 16 channels
+      f4 sT[NT], kf[NT];
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) {
+        sT[kt] = f4_zero();
+        kf[kt] = ld4(Ks_s + (16 * kt + j) * LDW + 16 * h + 4 * g);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) sT[kt] = mfma16(kf[kt][r], qT[h][r], sT[kt]);
+      // softmax over keys (registers x the 4 lane groups), scores / sqrt(16)
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) {
+        sT[kt] = sT[kt] * f4_splat(0.25f);
+        mx = fmaxf(mx, fmaxf(fmaxf(sT[kt].x, sT[kt].y), fmaxf(sT[kt].z, sT[kt].w)));
+      }
+      mx = max_over_g(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sT[kt][r] = __expf(sT[kt][r] - mx);
+        sum += (sT[kt].x + sT[kt].y) + (sT[kt].z + sT[kt].w);
+      }
+      const float inv = 1.0f / sum_over_g(sum);
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) sT[kt] = sT[kt] * f4_splat(inv);
+      // column sums over this wave's queries (for abar) and the query-0 row (for the weights)
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) {
+        if (t == 0) wacc[kt] = wacc[kt] + sT[kt];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float c = sT[kt][r];
+          c += __shfl_xor(c, 1);
+          c += __shfl_xor(c, 2);
+          c += __shfl_xor(c, 4);
+          c += __shfl_xor(c, 8);
+          if (j == 0) part[((slot * NT + t) * 4 + h) * S + 16 * kt + 4 * g + r] = c;
+        }
+      }
+      // O^T[h] = V_h^T . P^T : A = V (channels of head h on rows), B = P^T (keys in registers)
+      f4 o0 = f4_zero(), o1 = f4_zero();
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) {
+        const f4 vf = ld4(Vt_s + (16 * h + j) * LDV + 16 * kt + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if ((kt & 1) == 0) o0 = mfma16(vf[r], sT[kt][r], o0);
+          else o1 = mfma16(vf[r], sT[kt][r], o1);
+        }
+      }
+      oT[h] = o0 + o1;
+    }
+    f4 y[4];
+#pragma unroll
+    for (int M = 0; M < 4; ++M) y[M] = ld4(bO + 16 * M + 4 * g);
+    lin_T<4, 4>(Wo, LDW, oT, y, lane);
+    if (valid) {
+      const size_t orow = ((size_t)ray * S + 16 * t + j) * C64;
+#pragma unroll
+      for (int M = 0; M < 4; ++M) st4(x_out + orow + 16 * M + 4 * g, y[M] + x[M]);
+      if (weights != nullptr && t == 0 && j == 0) {  // head-mean of attention row 0 (:216)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+          st4(weights + (size_t)ray * S + 16 * kt + 4 * g, wacc[kt] * f4_splat(0.25f));
+      }
+    }
+    __syncthreads();
+    if (abar != nullptr) {
+      for (int idx = tid; idx < RPW * 4 * S; idx += NTHR) {
+        const int sl = idx / (4 * S), rem = idx - sl * 4 * S;  // rem = h*S + key
+        const int rr = grp * RPW + sl;
+        float c = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) c += part[(sl * NT + tt) * 4 * S + rem];
+        if (rr < R) abar[(size_t)rr * 4 * S + rem] = c * (1.0f / S);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------ semantic aggregation
+// One workgroup (256 threads) per ray; thread (half, c4) owns deep channels c4..c4+3 of the samples
+// s = half (mod 2).  Per (sample, view): attention weights of every layer are rebuilt from the stored
+// logits + softmax stats, summed into W3d / W2d (per 8-channel group), and applied to the bilinearly
+// sampled (or dense) 512-ch deep-semantic row.  Views whose weight is exactly 0 are skipped.
+__global__ void __launch_bounds__(256)
+k_sem(gpn_sem_args_t a) {
+  __shared__ float sP[GPN_MAX_VIEWS * 12];
+  __shared__ __attribute__((aligned(16))) float sPre[512];
+  const int tid = threadIdx.x;
+  const int r = blockIdx.x;
+  const int S = a.S, V = a.V;
+  if (a.deep_map != nullptr) {
+    for (int i = tid; i < V * 12; i += 256) sP[i] = a.proj[(i / 12) * 16 + (i % 12)];
+  }
+  __syncthreads();
+  const int half = tid >> 7, lt = tid & 127;
+  const int c4 = lt * 4, grp = lt >> 1, head = grp >> 4;
+  f4 acc2 = f4_zero();
+  const size_t rs = (size_t)a.deep_w * GPN_SEM;
+  for (int s = half; s < S; s += 2) {
+    const size_t n = (size_t)r * S + s;
+    bool any_vis = false;
+    for (int v = 0; v < V; ++v) any_vis |= a.mask[n * V + v] != 0.0f;
+    f4 acc3 = f4_zero();
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (a.deep_map != nullptr) px = a.xyz[n * 3 + 0], py = a.xyz[n * 3 + 1], pz = a.xyz[n * 3 + 2];
+    for (int v = 0; v < V; ++v) {
+      if (any_vis && a.mask[n * V + v] == 0.0f) continue;  // softmax weight is exactly 0
+      float w3 = 0.f, w2 = 0.f;
+      for (int l = 0; l < a.depth; ++l) {
+        const float lg = a.logits[l][(n * V + v) * C64 + grp];
+        const float m = a.stats[l][n * 128 + grp];
+        const float rl = a.stats[l][n * 128 + 64 + grp];
+        const float at = __expf(lg - m) * rl;
+        w3 += at;
+        w2 += a.abar[l][((size_t)r * 4 + head) * S + s] * at;
+      }
+      f4 d;
+      if (a.deep_dense != nullptr) {
+        d = ld4(a.deep_dense + (n * V + v) * GPN_SEM + c4);
+      } else {
+        const GpnPix pp = gpn_project(sP + v * 12, px, py, pz);
+        const GpnTaps t = gpn_taps(pp.px, pp.py, a.img_h, a.img_w, a.deep_h, a.deep_w);
+        const float* dm = a.deep_map + (size_t)v * a.deep_h * rs + c4;
+        const size_t o00 = (size_t)t.y0 * rs + (size_t)t.x0 * GPN_SEM;
+        f4 vnw = f4_zero(), vne = f4_zero(), vsw = f4_zero(), vse = f4_zero();
+        if (t.vy0 && t.vx0) vnw = ld4(dm + o00);
+        if (t.vy0 && t.vx1) vne = ld4(dm + o00 + GPN_SEM);
+        if (t.vy1 && t.vx0) vsw = ld4(dm + o00 + rs);
+        if (t.vy1 && t.vx1) vse = ld4(dm + o00 + rs + GPN_SEM);
+        d.x = gpn_bilerp(vnw.x, vne.x, vsw.x, vse.x, t);
+        d.y = gpn_bilerp(vnw.y, vne.y, vsw.y, vse.y, t);
+        d.z = gpn_bilerp(vnw.z, vne.z, vsw.z, vse.z, t);
+        d.w = gpn_bilerp(vnw.w, vne.w, vsw.w, vse.w, t);
+      }
+      acc3 = acc3 + d * f4_splat(w3);
+      acc2 = acc2 + d * f4_splat(w2);
+    }
+    if (a.sem3d != nullptr) st4(a.sem3d + n * GPN_SEM + c4, acc3);
+  }
+  if (half == 1) st4(sPre + c4, acc2);
+  __syncthreads();
+  if (half == 0) st4(a.pre + (size_t)r * GPN_SEM + c4, acc2 + ld4(sPre + c4));
+}
+
+// ------------------------------------------------------------------------------------ heads
+// One wave per ray: final LayerNorm (eps 1e-5), mean over samples, rgb_fc, cat with weights, depth.
+__global__ void __launch_bounds__(256)
+k_heads_rgb(const float* __restrict__ norm_w, const float* __restrict__ norm_b, gpn_linear_t rgb_fc,
+            const float* __restrict__ q, const float* __restrict__ weights,
+            const float* __restrict__ z_vals, int R, int S, float* __restrict__ out,
+            float* __restrict__ depth) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  // lane l owns channel l; each sample's 64 channels are normalised with a wave reduction
+  const float ga = norm_w[lane], be = norm_b[lane];
+  float hsum = 0.f, dsum = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const float x = q[((size_t)r * S + s) * C64 + lane];
+    float m = x;
+    for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o);
+    m *= (1.0f / 64.0f);
+    const float d = x - m;
+    float vv = d * d;
+    for (int o = 32; o > 0; o >>= 1) vv += __shfl_xor(vv, o);
+    vv *= (1.0f / 64.0f);
+    hsum += d * (1.0f / sqrtf(vv + 1e-5f)) * ga + be;
+  }
+  const float hmean = hsum / (float)S;
+  for (int c = 0; c < 3; ++c) {
+    float p = rgb_fc.w[c * C64 + lane] * hmean;
+    for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
+    if (lane == 0) out[(size_t)r * (3 + S) + c] = p + (rgb_fc.b ? rgb_fc.b[c] : 0.f);
+  }
+  for (int s = lane; s < S; s += 64) {
+    const float w = weights[(size_t)r * S + s];
+    out[(size_t)r * (3 + S) + 3 + s] = w;
+    if (z_vals != nullptr) dsum += w * z_vals[(size_t)r * S + s];
+  }
+  if (depth != nullptr && z_vals != nullptr) {
+    for (int o = 32; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o);
+    if (lane == 0) depth[r] = dsum;
+  }
+}
+
+// sem_feat = ReLU(W pre + b): [R,512] x [512,512]^T on MFMA; one wave per (16 rays, 128 outputs).
+__global__ void __launch_bounds__(256)
+k_sem_adaptor(gpn_linear_t fc, const float* __restrict__ pre, int R, float* __restrict__ sem_feat) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int r0 = blockIdx.x * 16;
+  const int rr = r0 + j;
+  const bool valid = rr < R;
+  const int rc = valid ? rr : R - 1;
+  f4 x[32];
+#pragma unroll
+  for (int T = 0; T < 32; ++T) x[T] = ld4(pre + (size_t)rc * GPN_SEM + 16 * T + 4 * g);
+  const float* wp = fc.w + (size_t)j * GPN_SEM + 4 * g;
+  for (int M0 = wave * 8; M0 < wave * 8 + 8; M0 += 4) {
+    f4 y[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      y[m] = fc.b ? ld4(fc.b + 16 * (M0 + m) + 4 * g) : f4_zero();
+#pragma unroll
+    for (int T = 0; T < 32; ++T) {
+      f4 w[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) w[m] = ld4(wp + (size_t)(16 * (M0 + m)) * GPN_SEM + 16 * T);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) y[m] = mfma16(w[m][r], x[T][r], y[m]);
+    }
+    if (valid) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        st4(sem_feat + (size_t)rr * GPN_SEM + 16 * (M0 + m) + 4 * g, f4_relu(y[m]));
+    }
+  }
+}
+
+// ==================================================================================== C-ABI
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+#define REQ_LIN(l, name) \
+  GPN_REQUIRE((l).w && aligned16((l).w), "%s: weight pointer null or not 16-byte aligned", name)
+
+extern "C" int gpn_posenc(const float* pts, const float* ray_d, int R, int S, float* emb,
+                          gpn_stream_t stream) {
+  GPN_REQUIRE(pts && ray_d && emb, "gpn_posenc: null pointer");
+  GPN_REQUIRE(R >= 0 && S >= 1, "gpn_posenc: bad shape");
+  const long long N = (long long)R * S;
+  if (N == 0) return GPN_OK;
+  hipLaunchKernelGGL(k_posenc, dim3(gpn_ceil_div(N * GPN_EMB, 256)), dim3(256), 0,
+                     (hipStream_t)stream, pts, ray_d, S, N, emb);
+  GPN_LAUNCH_CHECK("k_posenc");
+  return GPN_OK;
+}
+
+extern "C" int gpn_rgbfeat(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* rgb_feat,
+                           int N, int V, int in_ch, float* feat, float* q0, gpn_stream_t stream) {
+  GPN_REQUIRE(fc0 && fc2 && rgb_feat && feat && q0, "gpn_rgbfeat: null pointer");
+  REQ_LIN(*fc2, "gpn_rgbfeat.fc2");
+  GPN_REQUIRE(fc0->w, "gpn_rgbfeat: null weight");
+  GPN_REQUIRE(N >= 0 && V >= 1 && V <= GPN_MAX_VIEWS && in_ch >= 1 && in_ch <= 48,
+              "gpn_rgbfeat: need 1<=V<=%d, in_ch<=48 (got V=%d in_ch=%d)", GPN_MAX_VIEWS, V, in_ch);
+  GPN_REQUIRE(aligned16(feat) && aligned16(q0), "gpn_rgbfeat: outputs must be 16-byte aligned");
+  if (N == 0) return GPN_OK;
+  const size_t lds = sizeof(float) * (64 * RF_LD0 + 64 * LDW + 128);
+  const int grid = persistent_grid(((long long)N + 127) / 128);
+  hipLaunchKernelGGL(k_rgbfeat, dim3(grid), dim3(512), lds, (hipStream_t)stream, *fc0, *fc2,
+                     rgb_feat, (long long)N, V, in_ch, feat, q0);
+  GPN_LAUNCH_CHECK("k_rgbfeat");
+  return GPN_OK;
+}
+
+extern "C" int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const float* feat,
+                             const float* ray_diff, const float* mask, int N, int V, float* q_out,
+                             float* logits, float* stats, gpn_stream_t stream) {
+  GPN_REQUIRE(L && q_in && feat && ray_diff && mask && q_out, "gpn_view_attn: null pointer");
+  REQ_LIN(L->q, "gpn_view_attn.q");
+  REQ_LIN(L->k, "gpn_view_attn.k");
+  REQ_LIN(L->v, "gpn_view_attn.v");
+  REQ_LIN(L->out, "gpn_view_attn.out");
+  GPN_REQUIRE(L->pos0.w && L->pos2.w && L->attn0.w && L->attn2.w && L->attn_norm_w &&
+                  L->attn_norm_b, "gpn_view_attn: null weight");
+  GPN_REQUIRE(N >= 0 && V >= 1 && V <= GPN_MAX_VIEWS, "gpn_view_attn: need 1<=V<=%d (got %d)",
+              GPN_MAX_VIEWS, V);
+  GPN_REQUIRE(aligned16(q_in) && aligned16(feat) && aligned16(q_out) && aligned16(logits) &&
+                  aligned16(stats), "gpn_view_attn: tensors must be 16-byte aligned");
+  if (N == 0) return GPN_OK;
+  const size_t lds = sizeof(float) * VIEW_LDS_FLOATS;
+  int rc = set_lds_limit(reinterpret_cast<const void*>(k_view_attn), lds);
+  if (rc) return rc;
+  const int grid = persistent_grid(((long long)N + 127) / 128);
+  hipLaunchKernelGGL(k_view_attn, dim3(grid), dim3(512), lds, (hipStream_t)stream, *L, q_in, feat,
+                     ray_diff, mask, (long long)N, V, q_out, logits, stats);
+  GPN_LAUNCH_CHECK("k_view_attn");
+  return GPN_OK;
+}
+
+extern "C" int gpn_ff(const float* norm_w, const float* norm_b, const gpn_linear_t* fc1,
+                      const gpn_linear_t* fc2, const float* x_in, int N, float* x_out,
+                      gpn_stream_t stream) {
+  GPN_REQUIRE(norm_w && norm_b && fc1 && fc2 && x_in && x_out, "gpn_ff: null pointer");
+  REQ_LIN(*fc1, "gpn_ff.fc1");
+  REQ_LIN(*fc2, "gpn_ff.fc2");
+  GPN_REQUIRE(aligned16(x_in) && aligned16(x_out), "gpn_ff: tensors must be 16-byte aligned");
+  GPN_REQUIRE(N >= 0, "gpn_ff: bad N");
+  if (N == 0) return GPN_OK;
+  const size_t lds = sizeof(float) * FF_LDS_FLOATS;
+  int rc = set_lds_limit(reinterpret_cast<const void*>(k_ff), lds);
+  if (rc) return rc;
+  const int grid = persistent_grid(((long long)N + 127) / 128);
+  hipLaunchKernelGGL(k_ff, dim3(grid), dim3(512), lds, (hipStream_t)stream, norm_w, norm_b, *fc1,
+                     *fc2, x_in, (long long)N, x_out);
+  GPN_LAUNCH_CHECK("k_ff");
+  return GPN_OK;
+}
+
+extern "C" int gpn_qpos(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* q_in,
+                        const float* emb, int N, float* q_out, gpn_stream_t stream) {
+  GPN_REQUIRE(fc0 && fc2 && q_in && emb && q_out, "gpn_qpos: null pointer");
+  GPN_REQUIRE(fc0->w, "gpn_qpos: null weight");
+  REQ_LIN(*fc2, "gpn_qpos.fc2");
+  GPN_REQUIRE(aligned16(q_in) && aligned16(emb) && aligned16(q_out),
+              "gpn_qpos: tensors must be 16-byte aligned");
+  GPN_REQUIRE(N >= 0, "gpn_qpos: bad N");
+  if (N == 0) return GPN_OK;
+  const size_t lds = sizeof(float) * QP_LDS_FLOATS;
+  int rc = set_lds_limit(reinterpret_cast<const void*>(k_qpos), lds);
+  if (rc) return rc;
+  const int grid = persistent_grid(((long long)N + 127) / 128);
+  hipLaunchKernelGGL(k_qpos, dim3(grid), dim3(512), lds, (hipStream_t)stream, *fc0, *fc2, q_in, emb,
+                     (long long)N, q_out);
+  GPN_LAUNCH_CHECK("k_qpos");
+  return GPN_OK;
+}
+
+template <int NT>
+static int launch_ray_attn(const gpn_ray_layer_t* L, const float* x_in, int R, float* x_out,
+                           float* abar, float* weights, hipStream_t stream) {
+  using Cfg = RayCfg<NT>;
+  const size_t lds = sizeof(float) * Cfg::LDS_FLOATS;
+  int rc = set_lds_limit(reinterpret_cast<const void*>(k_ray_attn<NT>), lds);
+  if (rc) return rc;
+  const int grid = persistent_grid(((long long)R + Cfg::RPW - 1) / Cfg::RPW);
+  hipLaunchKernelGGL(k_ray_attn<NT>, dim3(grid), dim3(Cfg::THREADS), lds, stream, *L, x_in, R, x_out,
+                     abar, weights);
+  GPN_LAUNCH_CHECK("k_ray_attn");
+  return GPN_OK;
+}
+
+extern "C" int gpn_ray_attn(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,
+                            float* abar, float* weights, gpn_stream_t stream) {
+  GPN_REQUIRE(L && x_in && x_out, "gpn_ray_attn: null pointer");
+  REQ_LIN(L->q, "gpn_ray_attn.q");
+  REQ_LIN(L->k, "gpn_ray_attn.k");
+  REQ_LIN(L->v, "gpn_ray_attn.v");
+  REQ_LIN(L->out, "gpn_ray_attn.out");
+  GPN_REQUIRE(L->attn_norm_w && L->attn_norm_b, "gpn_ray_attn: null weight");
+  GPN_REQUIRE(R >= 0 && S >= 16 && S <= GPN_MAX_SAMPLES && S % 16 == 0,
+              "gpn_ray_attn: samples per ray must be a multiple of 16 in [16,%d] (got %d)",
+              GPN_MAX_SAMPLES, S);
+  GPN_REQUIRE(aligned16(x_in) && aligned16(x_out) && aligned16(weights),
+              "gpn_ray_attn: tensors must be 16-byte aligned");
+  if (R == 0) return GPN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  switch (S / 16) {
+    case 1: return launch_ray_attn<1>(L, x_in, R, x_out, abar, weights, st);
+    case 2: return launch_ray_attn<2>(L, x_in, R, x_out, abar, weights, st);
+    case 3: return launch_ray_attn<3>(L, x_in, R, x_out, abar, weights, st);
+    case 4: return launch_ray_attn<4>(L, x_in, R, x_out, abar, weights, st);
+    case 5: return launch_ray_attn<5>(L, x_in, R, x_out, abar, weights, st);
+    case 6: return launch_ray_attn<6>(L, x_in, R, x_out, abar, weights, st);
+    case 7: return launch_ray_attn<7>(L, x_in, R, x_out, abar, weights, st);
+    default: return launch_ray_attn<8>(L, x_in, R, x_out, abar, weights, st);
+  }
+}
+
+extern "C" int gpn_sem_aggregate(const gpn_sem_args_t* a, gpn_stream_t stream) {
+  GPN_REQUIRE(a, "gpn_sem_aggregate: null args");
+  GPN_REQUIRE(a->R >= 0 && a->S >= 1 && a->V >= 1 && a->V <= GPN_MAX_VIEWS && a->depth >= 1 &&
+                  a->depth <= GPN_MAX_DEPTH, "gpn_sem_aggregate: bad shape");
+  GPN_REQUIRE(a->mask && a->pre, "gpn_sem_aggregate: null pointer");
+  for (int l = 0; l < a->depth; ++l)
+    GPN_REQUIRE(a->logits[l] && a->stats[l] && a->abar[l], "gpn_sem_aggregate: null layer %d", l);
+  GPN_REQUIRE((a->deep_dense != nullptr) != (a->deep_map != nullptr),
+              "gpn_sem_aggregate: exactly one of deep_dense / deep_map must be given");
+  if (a->deep_map) {
+    GPN_REQUIRE(a->xyz && a->proj && a->deep_h >= 1 && a->deep_w >= 1 && a->img_h > 1 && a->img_w > 1,
+                "gpn_sem_aggregate: map mode needs xyz, proj and sizes");
+    GPN_REQUIRE(aligned16(a->deep_map), "gpn_sem_aggregate: deep_map must be 16-byte aligned");
+  } else {
+    GPN_REQUIRE(aligned16(a->deep_dense), "gpn_sem_aggregate: deep_dense must be 16-byte aligned");
+  }
+  GPN_REQUIRE(aligned16(a->pre) && aligned16(a->sem3d), "gpn_sem_aggregate: outputs must be aligned");
+  if (a->R == 0) return GPN_OK;
+  hipLaunchKernelGGL(k_sem, dim3(a->R), dim3(256), 0, (hipStream_t)stream, *a);
+  GPN_LAUNCH_CHECK("k_sem");
+  return GPN_OK;
+}
+
+extern "C" int gpn_heads(const gpn_gnt_weights_t* W, const float* q, const float* weights,
+                         const float* z_vals, const float* pre, int R, int S, float* out,
+                         float* depth, float* sem_feat, gpn_stream_t stream) {
+  GPN_REQUIRE(W && q && weights && out, "gpn_heads: null pointer");
+  GPN_REQUIRE(W->norm_w && W->norm_b && W->rgb_fc.w, "gpn_heads: null weight");
+  GPN_REQUIRE(R >= 0 && S >= 1, "gpn_heads: bad shape");
+  if (R == 0) return GPN_OK;
+  hipLaunchKernelGGL(k_heads_rgb, dim3(gpn_ceil_div(R, 4)), dim3(256), 0, (hipStream_t)stream,
+                     W->norm_w, W->norm_b, W->rgb_fc, q, weights, z_vals, R, S, out, depth);
+  GPN_LAUNCH_CHECK("k_heads_rgb");
+  if (pre != nullptr) {
+    GPN_REQUIRE(sem_feat, "gpn_heads: pre given without sem_feat");
+    REQ_LIN(W->sem_adaptor, "gpn_heads.sem_adaptor");
+    GPN_REQUIRE(aligned16(pre) && aligned16(sem_feat), "gpn_heads: sem tensors must be aligned");
+    hipLaunchKernelGGL(k_sem_adaptor, dim3(gpn_ceil_div(R, 16)), dim3(256), 0, (hipStream_t)stream,
+                       W->sem_adaptor, pre, R, sem_feat);
+    GPN_LAUNCH_CHECK("k_sem_adaptor");
+  }
+  return GPN_OK;
+}
+
+// ------------------------------------------------------------------------------------ whole forward
+static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct GntWs {
+  size_t emb, feat, q, logits, stats, abar, weights, pre, total;
+};
+static GntWs gnt_ws_layout(int R, int S, int V, int depth) {
+  const size_t N = (size_t)R * S, f = sizeof(float);
+  GntWs w;
+  size_t o = 0;
+  w.emb = o, o += align_up(N * GPN_EMB * f);
+  w.feat = o, o += align_up(N * V * C64 * f);
+  w.q = o, o += align_up(N * C64 * f);
+  w.logits = o, o += depth * align_up(N * V * C64 * f);
+  w.stats = o, o += depth * align_up(N * 128 * f);
+  w.abar = o, o += depth * align_up((size_t)R * 4 * S * f);
+  w.weights = o, o += align_up(N * f);
+  w.pre = o, o += align_up((size_t)R * GPN_SEM * f);
+  w.total = o;
+  return w;
+}
+
+extern "C" size_t gpn_gnt_workspace_bytes(int R, int S, int V, int depth) {
+  if (R < 0 || S < 1 || V < 1 || depth < 1) return 0;
+  return gnt_ws_layout(R, S, V, depth).total;
+}
+
+extern "C" int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat,
+                               const float* ray_diff, const float* mask, const float* pts,
+                               const float* ray_d, const float* z_vals, int R, int S, int V,
+                               gpn_sem_args_t* sem, float* out, float* depth, float* sem_feat,
+                               void* workspace, size_t workspace_bytes, gpn_stream_t stream) {
+  GPN_REQUIRE(W && rgb_feat && ray_diff && mask && pts && ray_d && out && workspace,
+              "gpn_gnt_forward: null pointer");
+  const int D = W->trans_depth;
+  GPN_REQUIRE(D >= 1 && D <= GPN_MAX_DEPTH, "gpn_gnt_forward: trans_depth must be in [1,%d]",
+              GPN_MAX_DEPTH);
+  GPN_REQUIRE(R >= 0 && S >= 16 && S % 16 == 0 && S <= GPN_MAX_SAMPLES && V >= 1 &&
+                  V <= GPN_MAX_VIEWS, "gpn_gnt_forward: unsupported shape R=%d S=%d V=%d", R, S, V);
+  const GntWs L = gnt_ws_layout(R, S, V, D);
+  GPN_REQUIRE(workspace_bytes >= L.total, "gpn_gnt_forward: workspace too small (%zu < %zu)",
+              workspace_bytes, L.total);
+  GPN_REQUIRE(aligned16(workspace), "gpn_gnt_forward: workspace must be 16-byte aligned");
+  if (sem) GPN_REQUIRE(sem_feat, "gpn_gnt_forward: sem given without sem_feat output");
+  if (R == 0) return GPN_OK;
+  char* ws = static_cast<char*>(workspace);
+  const size_t N = (size_t)R * S, f = sizeof(float);
+  float* emb = reinterpret_cast<float*>(ws + L.emb);
+  float* feat = reinterpret_cast<float*>(ws + L.feat);
+  float* q = reinterpret_cast<float*>(ws + L.q);
+  float* wts = reinterpret_cast<float*>(ws + L.weights);
+  float* pre = reinterpret_cast<float*>(ws + L.pre);
+  int rc;
+  if ((rc = gpn_posenc(pts, ray_d, R, S, emb, stream))) return rc;
+  if ((rc = gpn_rgbfeat(&W->rgbfeat0, &W->rgbfeat2, rgb_feat, (int)N, V, 3 + W->in_feat_ch, feat, q,
+                        stream)))
+    return rc;
+  for (int l = 0; l < D; ++l) {
+    float* lg = sem ? reinterpret_cast<float*>(ws + L.logits + l * align_up(N * V * C64 * f)) : nullptr;
+    float* st = sem ? reinterpret_cast<float*>(ws + L.stats + l * align_up(N * 128 * f)) : nullptr;
+    float* ab = sem ? reinterpret_cast<float*>(ws + L.abar + l * align_up((size_t)R * 4 * S * f)) : nullptr;
+    const gpn_view_layer_t* vl = &W->view[l];
+    const gpn_ray_layer_t* rl = &W->ray[l];
+    if ((rc = gpn_view_attn(vl, q, feat, ray_diff, mask, (int)N, V, q, lg, st, stream))) return rc;
+    if ((rc = gpn_ff(vl->ff_norm_w, vl->ff_norm_b, &vl->ff1, &vl->ff2, q, (int)N, q, stream))) return rc;
+    if (l % 2 == 0)
+      if ((rc = gpn_qpos(&W->qfc0[l], &W->qfc2[l], q, emb, (int)N, q, stream))) return rc;
+    if ((rc = gpn_ray_attn(rl, q, R, S, q, ab, l == D - 1 ? wts : nullptr, stream))) return rc;
+    if ((rc = gpn_ff(rl->ff_norm_w, rl->ff_norm_b, &rl->ff1, &rl->ff2, q, (int)N, q, stream))) return rc;
+    if (sem) sem->logits[l] = lg, sem->stats[l] = st, sem->abar[l] = ab;
+  }
+  if (sem) {
+    sem->R = R, sem->S = S, sem->V = V, sem->depth = D;
+    sem->mask = mask;
+    sem->pre = pre;
+    if ((rc = gpn_sem_aggregate(sem, stream))) return rc;
+  }
+  return gpn_heads(W, q, wts, z_vals, sem ? pre : nullptr, R, S, out, depth, sem_feat, stream);
+}

@@ -1,0 +1,152 @@
+// Register-resident fp32 MFMA building blocks for the GNT kernels (gfx950, wave64).
+//
+// Everything is built on v_mfma_f32_16x16x4_f32 (exact fp32: a k-ordered fmaf chain, 32-cycle issue):
+//   D[i][j] += sum_{kk<4} A[i][kk] * B[kk][j]
+//   lane l supplies A[i = l&15][kk = l>>4] and B[kk = l>>4][j = l&15] (one float each) and holds
+//   D[i = 4*(l>>4) + reg][j = l&15], reg = 0..3.
+//
+// "T-tile" convention (activations live transposed: channels on the accumulator rows, points on the
+// lanes): a tile covers 16 channels x 16 points; lane (j = l&15, g = l>>4) holds, in one f4,
+//   X[point j][channel 16*T + 4*g + r],  r = 0..3.
+// That is exactly the C/D layout, so the OUTPUT of one linear layer is directly the B operand of the
+// next (k-step r of tile T pairs weight column 16T+4g+r with register r): chains of per-point
+// linear layers never leave the register file, and per-channel elementwise work (bias, ReLU,
+// softmax over views, max over views) is lane-local.  LayerNorm over the 64 channels of a point
+// needs the 16 registers of a lane plus two cross-lane adds (lanes j, j+16, j+32, j+48).
+//
+// Weights are read from LDS as the A operand: lane (i, g) needs W[16M+i][16T+4g .. +3] = one
+// ds_read_b128 per 4 MFMAs; rows are padded by 4 floats so that the 16 rows of a tile hit distinct
+// 16-byte slots.
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f4 f4_zero() { return (f4){0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ f4 f4_splat(float v) { return (f4){v, v, v, v}; }
+__device__ __forceinline__ f4 f4_relu(f4 v) {
+  return (f4){fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+}
+__device__ __forceinline__ f4 f4_max(f4 a, f4 b) {
+  return (f4){fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)};
+}
+__device__ __forceinline__ f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
+__device__ __forceinline__ void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
+
+// y[M] += W[16M.., 16T..] . x[T]   (transposed orientation: x, y are T-tiles; W row-major in LDS with
+// leading dimension ldw floats).  y must be initialised (bias or zero) by the caller.
+template <int KT, int MT>
+__device__ __forceinline__ void lin_T(const float* W, int ldw, const f4* x, f4* y, int lane) {
+  const float* wp = W + (lane & 15) * ldw + 4 * (lane >> 4);
+  constexpr int MC = MT < 4 ? MT : 4;  // 4 independent accumulators per k-step hide the MFMA latency
+  static_assert(MT % MC == 0, "MT must be a multiple of the accumulator chunk");
+#pragma unroll
+  for (int M0 = 0; M0 < MT; M0 += MC) {
+    // software pipeline: the weight fragments of step T+1 are read while step T's MFMAs issue; the
+    // sched_barrier keeps hipcc from hoisting every ds_read of the unrolled chain to the top
+    // (which spills past 256 VGPRs).
+    f4 w[MC];
+#pragma unroll
+    for (int m = 0; m < MC; ++m) w[m] = ld4(wp + (16 * (M0 + m)) * ldw);
+#pragma unroll
+    for (int T = 0; T < KT; ++T) {
+      f4 wn[MC];
+      if (T + 1 < KT) {
+#pragma unroll
+        for (int m = 0; m < MC; ++m) wn[m] = ld4(wp + (16 * (M0 + m)) * ldw + 16 * (T + 1));
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int m = 0; m < MC; ++m) y[M0 + m] = mfma16(w[m][r], x[T][r], y[M0 + m]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (T + 1 < KT) {
+#pragma unroll
+        for (int m = 0; m < MC; ++m) w[m] = wn[m];
+      }
+    }
+  }
+}
+
+// Same product with the activation tile as the A operand: the result comes out in NORMAL orientation
+// (lane (j, g) holds Y[point 4g + reg][channel 16N + j]).  Used where the next product sums over points.
+template <int KT, int NT>
+__device__ __forceinline__ void lin_N(const float* W, int ldw, const f4* x, f4* y, int lane) {
+  const float* wp = W + (lane & 15) * ldw + 4 * (lane >> 4);
+#pragma unroll
+  for (int T = 0; T < KT; ++T) {
+    f4 w[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) w[n] = ld4(wp + (16 * n) * ldw + 16 * T);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) y[n] = mfma16(x[T][r], w[n][r], y[n]);
+  }
+}
+
+// Sum over the 4 lanes (j, g = 0..3) that share a point.
+__device__ __forceinline__ float sum_over_g(float v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+__device__ __forceinline__ float max_over_g(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16));
+  v = fmaxf(v, __shfl_xor(v, 32));
+  return v;
+}
+
+// LayerNorm over the 64 channels of each point, T-tiles in and out.  gamma/beta are [64] (LDS or
+// global), eps as in the reference (1e-6 inside the transformers, 1e-5 for the final norm).
+__device__ __forceinline__ void layernorm_T(const f4* x, f4* y, const float* gamma,
+                                            const float* beta, float eps, int lane) {
+  float s = 0.f;
+#pragma unroll
+  for (int T = 0; T < 4; ++T) s += (x[T].x + x[T].y) + (x[T].z + x[T].w);
+  const float mean = sum_over_g(s) * (1.0f / 64.0f);
+  float q = 0.f;
+#pragma unroll
+  for (int T = 0; T < 4; ++T) {
+    const f4 d = x[T] - f4_splat(mean);
+    q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+  }
+  const float var = sum_over_g(q) * (1.0f / 64.0f);
+  const float rstd = 1.0f / sqrtf(var + eps);
+  const int g = lane >> 4;
+#pragma unroll
+  for (int T = 0; T < 4; ++T) {
+    const f4 ga = ld4(gamma + 16 * T + 4 * g), be = ld4(beta + 16 * T + 4 * g);
+    y[T] = (x[T] - f4_splat(mean)) * f4_splat(rstd) * ga + be;
+  }
+}
+
+// Cooperative global -> LDS copy of a row-major [rows, cols] matrix into a padded image
+// (leading dimension ldw); cols % 4 == 0 and 16-byte aligned source rows.
+__device__ __forceinline__ void stage_matrix(float* dst, int ldw, const float* __restrict__ src,
+                                             int rows, int cols, int tid, int nthreads) {
+  const int c4n = cols >> 2;
+  for (int idx = tid; idx < rows * c4n; idx += nthreads) {
+    const int r = idx / c4n, c4 = idx - r * c4n;
+    st4(dst + r * ldw + 4 * c4, ld4(src + (size_t)r * cols + 4 * c4));
+  }
+}
+
+// Same, element-wise, zero-padding to [prow, pcol] (for the 8-wide hidden layers and odd widths).
+__device__ __forceinline__ void stage_padded(float* dst, int ldw, int prow, int pcol,
+                                             const float* __restrict__ src, int rows, int cols,
+                                             int tid, int nthreads) {
+  for (int idx = tid; idx < prow * pcol; idx += nthreads) {
+    const int r = idx / pcol, c = idx - r * pcol;
+    dst[r * ldw + c] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.0f;
+  }
+}
+
+__device__ __forceinline__ void stage_vector(float* dst, int padded, const float* __restrict__ src,
+                                             int n, int tid, int nthreads) {
+  for (int i = tid; i < padded; i += nthreads) dst[i] = (src != nullptr && i < n) ? src[i] : 0.0f;
+}

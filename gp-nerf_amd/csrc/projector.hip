@@ -1,0 +1,219 @@
+// Fused projector (north_star subsystem 1): world->pixel projection of every ray sample into V
+// source views, in-front / in-bounds mask, bilinear gather of RGB + 32-ch features (+ optionally the
+// 512-ch deep-semantic map) from NHWC maps, and the ray-direction-difference feature.
+// Replaces reference gpnerf/projection.py:31-139 (Projector.compute and helpers).
+// HBM-bound: NHWC maps make every tap a contiguous 128 B (features) / 2 KB (deep semantics) read;
+// outputs are written once, fully coalesced.  Built with -ffp-contract=off.
+#include "common.h"
+#include "proj_common.h"
+
+// ---------------------------------------------------------------- NCHW -> NHWC repack
+__global__ void k_repack_nhwc(const float* __restrict__ src, float* __restrict__ dst, int C,
+                              long long HW) {
+  __shared__ float tile[32][33];
+  const int v = blockIdx.z;
+  const long long p0 = (long long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const float* s = src + (size_t)v * C * HW;
+  float* d = dst + (size_t)v * C * HW;
+  const int tx = threadIdx.x, ty = threadIdx.y;  // 32 x 8
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k;
+    const long long p = p0 + tx;
+    tile[k][tx] = (c < C && p < HW) ? s[(size_t)c * HW + p] : 0.0f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const long long p = p0 + k;
+    const int c = c0 + tx;
+    if (c < C && p < HW) d[(size_t)p * C + c] = tile[tx][k];
+  }
+}
+
+// ---------------------------------------------------------------- RGB + feature gather, mask, ray_diff
+// 256 threads = 32 (point,view) pairs x 8 lanes; lane q of a pair owns feature channels 4q..4q+3.
+constexpr int PAIRS = 32;
+
+__global__ void __launch_bounds__(256)
+k_project_feat(gpn_project_args_t a, long long n_pairs) {
+  __shared__ float sP[GPN_MAX_VIEWS * 12];
+  __shared__ float sPos[GPN_MAX_VIEWS * 3];
+  __shared__ __attribute__((aligned(16))) float sOut[PAIRS * 36];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < a.V * 12; i += 256) sP[i] = a.proj[(i / 12) * 16 + (i % 12)];
+  for (int i = tid; i < a.V * 3; i += 256) sPos[i] = a.src_pos[i];
+  __syncthreads();
+  const int slot = tid >> 3, q = tid & 7;
+  const int OC = 3 + a.feat_c;  // 35
+  const bool gather = a.rgb_feat != nullptr;  // false: geometry only (pix / mask / ray_diff)
+
+  for (long long base = (long long)blockIdx.x * PAIRS; base < n_pairs;
+       base += (long long)gridDim.x * PAIRS) {
+    const long long pair = base + slot;
+    if (pair < n_pairs) {
+      const long long n = pair / a.V;
+      const int v = (int)(pair - n * a.V);
+      const float x = a.xyz[n * 3 + 0], y = a.xyz[n * 3 + 1], z = a.xyz[n * 3 + 2];
+      const GpnPix pp = gpn_project(sP + v * 12, x, y, z);
+      // 32-channel feature map, NHWC: one float4 per lane and tap
+      if (gather) {
+        const GpnTaps t = gpn_taps(pp.px, pp.py, a.img_h, a.img_w, a.feat_h, a.feat_w);
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* fm = a.feat + (size_t)v * a.feat_h * a.feat_w * a.feat_c + q * 4;
+        const size_t rs = (size_t)a.feat_w * a.feat_c;
+        const size_t o00 = (size_t)t.y0 * rs + (size_t)t.x0 * a.feat_c;
+        float4 vnw = zero4, vne = zero4, vsw = zero4, vse = zero4;
+        if (t.vy0 && t.vx0) vnw = *reinterpret_cast<const float4*>(fm + o00);
+        if (t.vy0 && t.vx1) vne = *reinterpret_cast<const float4*>(fm + o00 + a.feat_c);
+        if (t.vy1 && t.vx0) vsw = *reinterpret_cast<const float4*>(fm + o00 + rs);
+        if (t.vy1 && t.vx1) vse = *reinterpret_cast<const float4*>(fm + o00 + rs + a.feat_c);
+        float* o = sOut + slot * OC + 3 + q * 4;
+        o[0] = gpn_bilerp(vnw.x, vne.x, vsw.x, vse.x, t);
+        o[1] = gpn_bilerp(vnw.y, vne.y, vsw.y, vse.y, t);
+        o[2] = gpn_bilerp(vnw.z, vne.z, vsw.z, vse.z, t);
+        o[3] = gpn_bilerp(vnw.w, vne.w, vsw.w, vse.w, t);
+      }
+      if (q < 3) {  // RGB image [V,H,W,3], channel q
+        const GpnTaps t = gpn_taps(pp.px, pp.py, a.img_h, a.img_w, a.rgb_h, a.rgb_w);
+        const float* im = a.rgb + (size_t)v * a.rgb_h * a.rgb_w * 3 + q;
+        const size_t rs = (size_t)a.rgb_w * 3;
+        const size_t o00 = (size_t)t.y0 * rs + (size_t)t.x0 * 3;
+        float vnw = 0.f, vne = 0.f, vsw = 0.f, vse = 0.f;
+        if (gather && t.vy0 && t.vx0) vnw = im[o00];
+        if (gather && t.vy0 && t.vx1) vne = im[o00 + 3];
+        if (gather && t.vy1 && t.vx0) vsw = im[o00 + rs];
+        if (gather && t.vy1 && t.vx1) vse = im[o00 + rs + 3];
+        if (gather) sOut[slot * OC + q] = gpn_bilerp(vnw, vne, vsw, vse, t);
+        if (q == 0 && a.taps) {
+          a.taps[((size_t)v * a.N + n) * 2 + 0] = t.x0;
+          a.taps[((size_t)v * a.N + n) * 2 + 1] = t.y0;
+        }
+      } else if (q == 3) {  // mask (projection.py:133-138)
+        const bool m = pp.front && gpn_inbound(pp.px, pp.py, a.img_h, a.img_w);
+        if (a.mask) a.mask[pair] = m ? 1.0f : 0.0f;
+        if (a.front) a.front[(size_t)v * a.N + n] = pp.front ? 1 : 0;
+        if (a.pix) {
+          a.pix[((size_t)v * a.N + n) * 2 + 0] = pp.px;
+          a.pix[((size_t)v * a.N + n) * 2 + 1] = pp.py;
+        }
+      } else if (q == 4 && a.ray_diff) {  // ray_diff (projection.py:65-82)
+        float ax = a.qry_pos[0] - x, ay = a.qry_pos[1] - y, az = a.qry_pos[2] - z;
+        const float na = sqrtf(ax * ax + ay * ay + az * az) + 1e-6f;
+        ax /= na, ay /= na, az /= na;
+        float bx = sPos[v * 3 + 0] - x, by = sPos[v * 3 + 1] - y, bz = sPos[v * 3 + 2] - z;
+        const float nb = sqrtf(bx * bx + by * by + bz * bz) + 1e-6f;
+        bx /= nb, by /= nb, bz /= nb;
+        const float dx = ax - bx, dy = ay - by, dz = az - bz;
+        float nd = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float dot = ax * bx + ay * by + az * bz;
+        nd = nd < 1e-6f ? 1e-6f : nd;
+        *reinterpret_cast<float4*>(a.ray_diff + pair * 4) = make_float4(dx / nd, dy / nd, dz / nd, dot);
+      }
+    }
+    if (!gather) continue;  // uniform across the block
+    __syncthreads();
+    // coalesced copy-out of this block's contiguous [pairs, OC] span
+    const long long left = n_pairs - base;
+    const int cnt = (int)(left < PAIRS ? left : PAIRS) * OC;
+    float* dst = a.rgb_feat + base * OC;
+    if (((base * OC) & 3) == 0) {
+      for (int i = tid * 4; i + 3 < cnt; i += 256 * 4)
+        *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(sOut + i);
+      for (int i = (cnt & ~3) + tid; i < cnt; i += 256) dst[i] = sOut[i];
+    } else {
+      for (int i = tid; i < cnt; i += 256) dst[i] = sOut[i];
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------- 512-channel deep-semantic gather
+// One wave per (point, view) pair; each lane owns 2 x float4 of the 512 channels: every tap is two
+// fully coalesced 1 KiB wave loads, the output row two 1 KiB wave stores.
+__global__ void __launch_bounds__(256)
+k_project_deep(gpn_project_args_t a, long long n_pairs) {
+  __shared__ float sP[GPN_MAX_VIEWS * 12];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < a.V * 12; i += 256) sP[i] = a.proj[(i / 12) * 16 + (i % 12)];
+  __syncthreads();
+  const int lane = tid & 63;
+  const long long wave = (long long)blockIdx.x * 4 + (tid >> 6);
+  const long long nwaves = (long long)gridDim.x * 4;
+  const int D = a.deep_c;  // 512
+  const size_t rs = (size_t)a.deep_w * D;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long long pair = wave; pair < n_pairs; pair += nwaves) {
+    const long long n = pair / a.V;
+    const int v = (int)(pair - n * a.V);
+    const GpnPix pp = gpn_project(sP + v * 12, a.xyz[n * 3 + 0], a.xyz[n * 3 + 1], a.xyz[n * 3 + 2]);
+    const GpnTaps t = gpn_taps(pp.px, pp.py, a.img_h, a.img_w, a.deep_h, a.deep_w);
+    const float* dm = a.deep + (size_t)v * a.deep_h * rs;
+    const size_t o00 = (size_t)t.y0 * rs + (size_t)t.x0 * D;
+    float* out = a.deep_out + pair * D;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int c = half * 256 + lane * 4;
+      float4 vnw = zero4, vne = zero4, vsw = zero4, vse = zero4;
+      if (t.vy0 && t.vx0) vnw = *reinterpret_cast<const float4*>(dm + o00 + c);
+      if (t.vy0 && t.vx1) vne = *reinterpret_cast<const float4*>(dm + o00 + D + c);
+      if (t.vy1 && t.vx0) vsw = *reinterpret_cast<const float4*>(dm + o00 + rs + c);
+      if (t.vy1 && t.vx1) vse = *reinterpret_cast<const float4*>(dm + o00 + rs + D + c);
+      float4 o;
+      o.x = gpn_bilerp(vnw.x, vne.x, vsw.x, vse.x, t);
+      o.y = gpn_bilerp(vnw.y, vne.y, vsw.y, vse.y, t);
+      o.z = gpn_bilerp(vnw.z, vne.z, vsw.z, vse.z, t);
+      o.w = gpn_bilerp(vnw.w, vne.w, vsw.w, vse.w, t);
+      *reinterpret_cast<float4*>(out + c) = o;
+    }
+  }
+}
+
+extern "C" int gpn_repack_nhwc(const float* src, float* dst, int V, int C, int H, int W,
+                               gpn_stream_t stream) {
+  GPN_REQUIRE(src && dst, "gpn_repack_nhwc: null pointer");
+  GPN_REQUIRE(V >= 1 && C >= 1 && H >= 1 && W >= 1 && V <= 65535, "gpn_repack_nhwc: bad shape");
+  const long long HW = (long long)H * W;
+  dim3 grid(gpn_ceil_div(HW, 32), gpn_ceil_div(C, 32), V);
+  GPN_REQUIRE(grid.y <= 65535, "gpn_repack_nhwc: too many channels");
+  hipLaunchKernelGGL(k_repack_nhwc, grid, dim3(32, 8), 0, (hipStream_t)stream, src, dst, C, HW);
+  GPN_LAUNCH_CHECK("k_repack_nhwc");
+  return GPN_OK;
+}
+
+extern "C" int gpn_project_gather(const gpn_project_args_t* a, gpn_stream_t stream) {
+  GPN_REQUIRE(a, "gpn_project_gather: null args");
+  GPN_REQUIRE(a->xyz && a->proj && a->src_pos, "gpn_project_gather: null pointer");
+  GPN_REQUIRE(a->N >= 0 && a->V >= 1 && a->V <= GPN_MAX_VIEWS,
+              "gpn_project_gather: need 1 <= V <= %d (got %d)", GPN_MAX_VIEWS, a->V);
+  GPN_REQUIRE(a->rgb_h >= 1 && a->rgb_w >= 1, "gpn_project_gather: bad rgb map size");
+  if (a->rgb_feat) {
+    GPN_REQUIRE(a->rgb && a->feat, "gpn_project_gather: rgb_feat requested without maps");
+    GPN_REQUIRE(a->feat_c == 32, "gpn_project_gather: feature maps must have 32 channels (got %d)",
+                a->feat_c);
+    GPN_REQUIRE(a->feat_h >= 1 && a->feat_w >= 1, "gpn_project_gather: bad feature map size");
+  }
+  GPN_REQUIRE(a->img_h > 1.0f && a->img_w > 1.0f, "gpn_project_gather: bad image size");
+  const bool want_deep = a->deep_out != nullptr;
+  if (want_deep) {
+    GPN_REQUIRE(a->deep, "gpn_project_gather: deep_out requested without a deep map");
+    GPN_REQUIRE(a->deep_c == GPN_SEM && a->deep_h >= 1 && a->deep_w >= 1,
+                "gpn_project_gather: deep-semantic maps must have %d channels (got %d)", GPN_SEM,
+                a->deep_c);
+  }
+  if (a->N == 0) return GPN_OK;
+  const long long n_pairs = (long long)a->N * a->V;
+  const int cus = gpn_num_cus();
+  {
+    const long long blocks = (n_pairs + PAIRS - 1) / PAIRS;
+    const int grid = (int)(blocks < (long long)cus * 16 ? blocks : (long long)cus * 16);
+    hipLaunchKernelGGL(k_project_feat, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, n_pairs);
+    GPN_LAUNCH_CHECK("k_project_feat");
+  }
+  if (want_deep) {
+    const long long blocks = (n_pairs + 3) / 4;
+    const int grid = (int)(blocks < (long long)cus * 8 ? blocks : (long long)cus * 8);
+    hipLaunchKernelGGL(k_project_deep, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, n_pairs);
+    GPN_LAUNCH_CHECK("k_project_deep");
+  }
+  return GPN_OK;
+}

@@ -1,0 +1,158 @@
+"""Image-level rendering -- same interface as reference gpnerf/render_image.py:6-121.
+
+`render_single_image` keeps the reference's chunk loop semantics and return structure (CPU tensors
+reshaped to [H', W', .]), but accumulates chunk results on the device and copies each output to the
+host once at the end instead of once per chunk.  `render_image_sharded` is the multi-GPU form
+(north_star subsystem 4): ranks render disjoint row blocks of the strided pixel grid and the
+rgb / depth / semantic tiles are all-gathered with RCCL (`torch.distributed`, backend "nccl").
+"""
+from collections import OrderedDict
+
+import torch
+
+from .render_ray import render_rays
+
+_SHARED_KEYS = ("camera", "depth_range", "src_rgbs", "src_cameras", "labels", "src_labels")
+
+
+def _render_chunks(ray_batch, model, projector, chunk_size, N_samples, inv_uniform, N_importance,
+                   det, white_bkgd, featmaps, deep_semantics, ret_alpha, single_net, start, stop,
+                   feats_out_3d=True):
+    """Chunk loop (reference render_image.py:39-85) over rays [start, stop); results stay on the
+    device: {'outputs_coarse': {k: [chunks]}, 'outputs_fine': ... or None}."""
+    acc = OrderedDict([("outputs_coarse", OrderedDict()), ("outputs_fine", OrderedDict())])
+    for i in range(start, stop, chunk_size):
+        j = min(i + chunk_size, stop)
+        chunk = OrderedDict()
+        for k in ray_batch:
+            if k in _SHARED_KEYS:
+                chunk[k] = ray_batch[k]
+            elif ray_batch[k] is not None:
+                chunk[k] = ray_batch[k][i:j]
+            else:
+                chunk[k] = None
+        ret = render_rays(chunk, model, featmaps, ref_deep_semantics=deep_semantics,
+                          projector=projector, N_samples=N_samples, inv_uniform=inv_uniform,
+                          N_importance=N_importance, det=det, white_bkgd=white_bkgd,
+                          ret_alpha=ret_alpha, single_net=single_net, feats_out_3d=feats_out_3d)
+        for lvl in ("outputs_coarse", "outputs_fine"):
+            if ret[lvl] is None:
+                acc[lvl] = None
+                continue
+            for k, v in ret[lvl].items():
+                if v is not None:
+                    acc[lvl].setdefault(k, []).append(v)
+    return acc
+
+
+def _strided_hw(ray_sampler, render_stride):
+    return (len(range(0, ray_sampler.H, render_stride)), len(range(0, ray_sampler.W, render_stride)))
+
+
+def _merge(acc, Hs, Ws):
+    """concat + reshape (reference render_image.py:87-119)."""
+    for lvl in ("outputs_coarse", "outputs_fine"):
+        if acc[lvl] is None:
+            continue
+        for k in list(acc[lvl]):
+            if k == "random_sigma":
+                continue
+            cat = torch.cat(acc[lvl][k], dim=0).cpu()
+            if k == "feats_out":
+                acc[lvl][k] = cat.reshape((Hs, Ws, 512, -1)).squeeze()
+            else:
+                acc[lvl][k] = cat.reshape((Hs, Ws, -1)).squeeze()
+    return acc
+
+
+def render_single_image(
+    ray_sampler,
+    ray_batch,
+    model,
+    projector,
+    chunk_size,
+    N_samples,
+    inv_uniform=False,
+    N_importance=0,
+    det=False,
+    white_bkgd=False,
+    render_stride=1,
+    featmaps=None,
+    deep_semantics=None,
+    ret_alpha=False,
+    single_net=False,
+    feats_out_3d=True,
+):
+    """reference render_image.py:6-121 -> {'outputs_coarse': {...}, 'outputs_fine': {...}} of CPU
+    tensors: rgb [H',W',3], depth [H',W'], weights [H',W',S], feats_out [H',W',512],
+    feats_out_3d [H',W',S*512] (skipped with the extension flag feats_out_3d=False)."""
+    N_rays = ray_batch["ray_o"].shape[0]
+    acc = _render_chunks(ray_batch, model, projector, chunk_size, N_samples, inv_uniform,
+                         N_importance, det, white_bkgd, featmaps, deep_semantics, ret_alpha,
+                         single_net, 0, N_rays, feats_out_3d)
+    Hs, Ws = _strided_hw(ray_sampler, render_stride)
+    return _merge(acc, Hs, Ws)
+
+
+def shard_rows(Hs, world_size):
+    """Row-aligned partition of the strided pixel grid: every rank gets ceil(Hs/G) rows (the last
+    ranks may own fewer / zero real rows; tiles are padded so that all-gather sizes are equal)."""
+    rows = (Hs + world_size - 1) // world_size
+    return rows, [(min(r * rows, Hs), min((r + 1) * rows, Hs)) for r in range(world_size)]
+
+
+GATHER_KEYS = ("rgb", "depth", "feats_out")
+
+
+def render_image_sharded(ray_sampler, ray_batch, model, projector, chunk_size, N_samples,
+                         inv_uniform=False, N_importance=0, det=False, white_bkgd=False,
+                         render_stride=1, featmaps=None, deep_semantics=None, ret_alpha=False,
+                         single_net=False, group=None, gather_weights=False, render_fn=None):
+    """Multi-GPU render_single_image: rank k renders rows [k*rows, (k+1)*rows) of the strided grid
+    (source maps, cameras and weights replicated), then one all_gather_into_tensor per output level
+    moves rgb[3] + depth[1] + feats_out[512] (+ weights[S]) per ray.  feats_out_3d is never
+    gathered.  Returns device tensors shaped like render_single_image's outputs on every rank.
+    `render_fn` (tests only) replaces the per-rank chunk renderer."""
+    import torch.distributed as dist
+
+    G = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    Hs, Ws = _strided_hw(ray_sampler, render_stride)
+    rows, parts = shard_rows(Hs, G)
+    r0, r1 = parts[rank]
+    fn = render_fn or _render_chunks
+    acc = fn(ray_batch, model, projector, chunk_size, N_samples, inv_uniform, N_importance, det,
+             white_bkgd, featmaps, deep_semantics, ret_alpha, single_net, r0 * Ws, r1 * Ws, False)
+    dev = ray_batch["ray_o"].device
+    out = OrderedDict()
+    for lvl in ("outputs_coarse", "outputs_fine"):
+        if acc[lvl] is None:
+            out[lvl] = None
+            continue
+        keys = [k for k in GATHER_KEYS if k in acc[lvl]]
+        if gather_weights and "weights" in acc[lvl]:
+            keys.append("weights")
+        cols = []
+        for k in keys:
+            t = torch.cat(acc[lvl][k], dim=0) if acc[lvl][k] else None
+            cols.append(t.reshape(t.shape[0], -1) if t is not None else None)
+        widths = [c.shape[1] for c in cols] if r1 > r0 else None
+        if widths is None:  # a rank without rows still has to know the tile width
+            widths = [3, 1, 512][:len(keys)]
+            if len(keys) > 3:
+                widths.append(N_samples + (N_importance if lvl == "outputs_fine" else 0))
+        tile = torch.zeros((rows * Ws, sum(widths)), device=dev)
+        if r1 > r0:
+            tile[: (r1 - r0) * Ws] = torch.cat(cols, dim=1)
+        if G > 1:
+            full = torch.empty((G * rows * Ws, tile.shape[1]), device=dev)
+            dist.all_gather_into_tensor(full, tile, group=group)
+        else:
+            full = tile
+        full = full[: Hs * Ws]
+        out[lvl] = OrderedDict()
+        o = 0
+        for k, wdt in zip(keys, widths):
+            out[lvl][k] = full[:, o:o + wdt].reshape(Hs, Ws, wdt).squeeze()
+            o += wdt
+    return out

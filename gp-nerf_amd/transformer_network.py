@@ -1,0 +1,233 @@
+"""`GNT` -- same constructor, parameter names (state-dict contract) and forward
+signature as reference gpnerf/transformer_network.py:221-338; the forward pass runs entirely in the
+fp32-MFMA HIP kernels of csrc/gnt.hip through `gpn_gnt_forward`.
+
+Inference only (eval-mode semantics: the reference's Dropout(0.1) layers are identities in eval,
+reference eval_gpnerf.py:172); no autograd graph is built.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class _Lin(nn.Module):
+    """Parameter holder with nn.Linear's parameter names and default init."""
+
+    def __init__(self, n_in, n_out, bias=True):
+        super().__init__()
+        ref = nn.Linear(n_in, n_out, bias=bias)
+        self.weight = ref.weight
+        if bias:
+            self.bias = ref.bias
+        else:
+            self.register_parameter("bias", None)
+
+
+class _Norm(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+
+class _Seq(nn.Module):
+    """Holds children under the numeric names nn.Sequential would give them ('0', '2')."""
+
+    def __init__(self, first, second):
+        super().__init__()
+        self.add_module("0", first)
+        self.add_module("2", second)
+
+    def __getitem__(self, i):
+        return getattr(self, str(i))
+
+
+class _FF(nn.Module):
+    def __init__(self, dim, hid):
+        super().__init__()
+        self.fc1 = _Lin(dim, hid)
+        self.fc2 = _Lin(hid, dim)
+
+
+class _ViewAttn(nn.Module):  # Attention2D (reference :55-72)
+    def __init__(self, dim):
+        super().__init__()
+        self.q_fc = _Lin(dim, dim, bias=False)
+        self.k_fc = _Lin(dim, dim, bias=False)
+        self.v_fc = _Lin(dim, dim, bias=False)
+        self.pos_fc = _Seq(_Lin(4, dim // 8), _Lin(dim // 8, dim))
+        self.attn_fc = _Seq(_Lin(dim, dim // 8), _Lin(dim // 8, dim))
+        self.out_fc = _Lin(dim, dim)
+
+
+class _RayAttn(nn.Module):  # Attention, attn_mode='qk' (reference :130-147)
+    def __init__(self, dim):
+        super().__init__()
+        self.q_fc = _Lin(dim, dim, bias=False)
+        self.k_fc = _Lin(dim, dim, bias=False)
+        self.v_fc = _Lin(dim, dim, bias=False)
+        self.out_fc = _Lin(dim, dim)
+
+
+class _Block(nn.Module):  # Transformer2D / Transformer (reference :97-104, :191-200)
+    def __init__(self, dim, attn):
+        super().__init__()
+        self.attn_norm = _Norm(dim)
+        self.ff_norm = _Norm(dim)
+        self.ff = _FF(dim, 4 * dim)
+        self.attn = attn
+
+
+def _lin(mod):
+    s = _lib.Linear()
+    s.w = mod.weight.data_ptr()
+    s.b = mod.bias.data_ptr() if mod.bias is not None else None
+    return s
+
+
+class GNT(nn.Module):
+    def __init__(self, args, in_feat_ch=32, posenc_dim=3, viewenc_dim=3, ret_alpha=False):
+        super().__init__()
+        C_ = args.netwidth
+        if C_ != _lib.NETWIDTH:
+            raise ValueError("the HIP kernels are built for netwidth=64 (got %d)" % C_)
+        if args.trans_depth > _lib.MAX_DEPTH:
+            raise ValueError("trans_depth must be <= %d" % _lib.MAX_DEPTH)
+        if posenc_dim != 63 or viewenc_dim != 63:
+            # The reference's own default (3, 3) does not match its embedders (63 + 63 channels,
+            # transformer_network.py:276-291) and crashes at q_fcs; every driver passes 63/63.
+            raise ValueError("posenc_dim and viewenc_dim must be 63 (10 frequencies, include_input)")
+        self.rgbfeat_fc = _Seq(_Lin(in_feat_ch + 3, C_), _Lin(C_, C_))
+        self.view_selftrans = nn.ModuleList()       # ray transformers (reference naming, :230)
+        self.view_sem_selftrans = nn.ModuleList()   # empty in the reference too (:232)
+        self.view_crosstrans = nn.ModuleList()      # view transformers
+        self.q_fcs = nn.ModuleList()
+        for i in range(args.trans_depth):
+            self.view_crosstrans.append(_Block(C_, _ViewAttn(C_)))
+            self.view_selftrans.append(_Block(C_, _RayAttn(C_)))
+            if i % 2 == 0:
+                self.q_fcs.append(_Seq(_Lin(C_ + posenc_dim + viewenc_dim, C_), _Lin(C_, C_)))
+            else:
+                self.q_fcs.append(nn.Identity())
+        self.posenc_dim, self.viewenc_dim = posenc_dim, viewenc_dim
+        self.ret_alpha = ret_alpha
+        self.save_feature = getattr(args, "save_feature", False)
+        self.norm = _Norm(C_)
+        self.rgb_fc = _Lin(C_, 3)
+        self.semantic_model = getattr(args, "semantic_model", "fpn")
+        if self.semantic_model == "fc":  # dead head kept for state-dict compatibility (:272-273)
+            self.semantic_fc = _Lin(C_, args.num_classes + 1)
+        self.semantic_adaptor = nn.ModuleList([_Lin(_lib.SEM, _lib.SEM)])  # 'semantic_adaptor.0.*'
+        self.trans_depth = args.trans_depth
+        self.in_feat_ch = in_feat_ch
+        self._wcache = None
+        self._ws = None
+
+    # ------------------------------------------------------------------ weights -> C struct
+    def _weights(self):
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._wcache is not None and self._wcache[0] == key:
+            return self._wcache[1]
+        for n, p in self.named_parameters():
+            if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError("GNT parameter %s must be a contiguous fp32 HIP tensor (move the "
+                                   "module with .cuda(); there is no CPU fallback)" % n)
+            if p.data_ptr() % 16:
+                raise RuntimeError("GNT parameter %s is not 16-byte aligned" % n)
+        W = _lib.GntWeights()
+        W.trans_depth, W.in_feat_ch = self.trans_depth, self.in_feat_ch
+        W.rgbfeat0, W.rgbfeat2 = _lin(self.rgbfeat_fc[0]), _lin(self.rgbfeat_fc[2])
+        for i in range(self.trans_depth):
+            b, L = self.view_crosstrans[i], W.view[i]
+            L.attn_norm_w, L.attn_norm_b = b.attn_norm.weight.data_ptr(), b.attn_norm.bias.data_ptr()
+            L.ff_norm_w, L.ff_norm_b = b.ff_norm.weight.data_ptr(), b.ff_norm.bias.data_ptr()
+            L.ff1, L.ff2 = _lin(b.ff.fc1), _lin(b.ff.fc2)
+            L.q, L.k, L.v = _lin(b.attn.q_fc), _lin(b.attn.k_fc), _lin(b.attn.v_fc)
+            L.pos0, L.pos2 = _lin(b.attn.pos_fc[0]), _lin(b.attn.pos_fc[2])
+            L.attn0, L.attn2 = _lin(b.attn.attn_fc[0]), _lin(b.attn.attn_fc[2])
+            L.out = _lin(b.attn.out_fc)
+            b, L = self.view_selftrans[i], W.ray[i]
+            L.attn_norm_w, L.attn_norm_b = b.attn_norm.weight.data_ptr(), b.attn_norm.bias.data_ptr()
+            L.ff_norm_w, L.ff_norm_b = b.ff_norm.weight.data_ptr(), b.ff_norm.bias.data_ptr()
+            L.ff1, L.ff2 = _lin(b.ff.fc1), _lin(b.ff.fc2)
+            L.q, L.k, L.v = _lin(b.attn.q_fc), _lin(b.attn.k_fc), _lin(b.attn.v_fc)
+            L.out = _lin(b.attn.out_fc)
+            if i % 2 == 0:
+                W.qfc0[i], W.qfc2[i] = _lin(self.q_fcs[i][0]), _lin(self.q_fcs[i][2])
+        W.norm_w, W.norm_b = self.norm.weight.data_ptr(), self.norm.bias.data_ptr()
+        W.rgb_fc = _lin(self.rgb_fc)
+        W.sem_adaptor = _lin(self.semantic_adaptor[0])
+        self._wcache = (key, W)
+        return W
+
+    def _workspace(self, R, S, V, dev):
+        need = _lib.lib().gpn_gnt_workspace_bytes(R, S, V, self.trans_depth)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        return self._ws, need
+
+    # ------------------------------------------------------------------ kernels
+    def run(self, rgb_feat, ray_diff, mask, pts, ray_d, z_vals=None, deep_dense=None, deep_map=None,
+            want_sem3d=True):
+        """Shared driver of `forward` (materialised deep_sem) and render_rays' fused path (deep maps).
+
+        deep_map: dict(map=[V,Hs,Ws,512] NHWC, proj=[V,4,4], img_h, img_w) or None.
+        Returns out [R,3+S], depth [R] or None, sem_feat [R,512] or None, sem_feat_3d or None."""
+        rgb_feat = _lib.dev_f32(_lib.as_f32c(rgb_feat), "rgb_feat")
+        R, S, V = rgb_feat.shape[:3]
+        if rgb_feat.shape[3] != 3 + self.in_feat_ch:
+            raise ValueError("rgb_feat must have %d channels" % (3 + self.in_feat_ch))
+        dev = rgb_feat.device
+        ray_diff = _lib.dev_f32(_lib.as_f32c(ray_diff), "ray_diff", (R, S, V, 4))
+        mask = _lib.dev_f32(_lib.as_f32c(mask), "mask").reshape(R, S, V)
+        pts = _lib.dev_f32(_lib.as_f32c(pts), "pts", (R, S, 3))
+        ray_d = _lib.dev_f32(_lib.as_f32c(ray_d), "ray_d", (R, 3))
+        if S % 16 or S < 16 or S > _lib.MAX_SAMPLES:
+            raise ValueError("samples per ray must be a multiple of 16 in [16,%d] (got %d)"
+                             % (_lib.MAX_SAMPLES, S))
+        W = self._weights()
+        ws, need = self._workspace(R, S, V, dev)
+        out = torch.empty((R, 3 + S), device=dev)
+        depth = torch.empty((R,), device=dev) if z_vals is not None else None
+        if z_vals is not None:
+            z_vals = _lib.dev_f32(_lib.as_f32c(z_vals), "z_vals", (R, S))
+        sem = sem_feat = sem3d = None
+        keep = []
+        if deep_dense is not None or deep_map is not None:
+            sem = _lib.SemArgs()
+            sem_feat = torch.empty((R, _lib.SEM), device=dev)
+            if want_sem3d:
+                sem3d = torch.empty((R, S, _lib.SEM), device=dev)
+                sem.sem3d = _lib.ptr(sem3d)
+            if deep_dense is not None:
+                dd = _lib.dev_f32(_lib.as_f32c(deep_dense), "deep_sem_feat", (R, S, V, _lib.SEM))
+                keep.append(dd)
+                sem.deep_dense = _lib.ptr(dd)
+            else:
+                m = _lib.dev_f32(deep_map["map"], "deep map")
+                if m.shape[0] != V or m.shape[3] != _lib.SEM:
+                    raise ValueError("deep map must be [V,Hs,Ws,512] NHWC")
+                sem.deep_map, sem.deep_h, sem.deep_w = _lib.ptr(m), m.shape[1], m.shape[2]
+                sem.xyz, sem.proj = _lib.ptr(pts), _lib.ptr(deep_map["proj"])
+                sem.img_h, sem.img_w = deep_map["img_h"], deep_map["img_w"]
+        _lib.check(_lib.lib().gpn_gnt_forward(
+            C.byref(W), _lib.ptr(rgb_feat), _lib.ptr(ray_diff), _lib.ptr(mask), _lib.ptr(pts),
+            _lib.ptr(ray_d), _lib.ptr(z_vals), R, S, V, C.byref(sem) if sem is not None else None,
+            _lib.ptr(out), _lib.ptr(depth), _lib.ptr(sem_feat), _lib.ptr(ws), need, _lib.stream()),
+            "gpn_gnt_forward")
+        return out, depth, sem_feat, sem3d
+
+    @torch.no_grad()
+    def forward(self, rgb_feat, deep_sem_feat, ray_diff, mask, pts, ray_d):
+        """reference transformer_network.py:295-338 ->
+        (cat[rgb, weights] [R,3+S], sem_feat [R,512], sem_feat_3d [R,S,512])."""
+        if not self.ret_alpha:
+            # reference :319/:326 unpack a tuple that only exists with ret_alpha=True
+            raise RuntimeError("GNT must be built with ret_alpha=True (the reference forward cannot "
+                               "run otherwise)")
+        out, _, sem_feat, sem3d = self.run(rgb_feat, ray_diff, mask, pts, ray_d,
+                                           deep_dense=deep_sem_feat)
+        return out, sem_feat, sem3d

@@ -1,0 +1,214 @@
+/*
+ * gpnerf_hip.h -- C-ABI of libgpnerf_hip.so: hand-written gfx950 (MI355X) HIP kernels for the
+ * per-ray rendering hot path of GP-NeRF.
+ *
+ * The reference (lifuguan/GP-NeRF) is pure Python/PyTorch and has no FFI; the boundary it offers
+ * is the set of Python functions listed in SURVEY.md section 8(b).  Each entry point below names the
+ * reference function (file:line under the reference repo) whose arithmetic it replaces.  The
+ * Python host (`gp-nerf_amd/`) binds these with ctypes and re-exposes the reference signatures.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless stated otherwise;
+ *   - `stream` is a hipStream_t (0 = default stream); every call only enqueues work;
+ *   - no entry point allocates, frees or synchronises; workspaces are passed in by the caller;
+ *   - return value: 0 on success, negative GPN_E_* on error (gpn_last_error() has the text);
+ *   - N = R*S points in ray-major order (point n = r*S + s), V source views.
+ */
+#ifndef GPNERF_HIP_H
+#define GPNERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPN_ABI_VERSION 1
+#define GPN_OK 0
+#define GPN_E_ARG (-1)     /* invalid argument (shape / null pointer / unsupported size) */
+#define GPN_E_LAUNCH (-2)  /* HIP reported an error at launch */
+
+#define GPN_C 64         /* netwidth (reference config.py:108) */
+#define GPN_SEM 512      /* deep-semantic channels (hard-coded in reference render_image.py:95) */
+#define GPN_EMB 128      /* pos-enc(63) + view-enc(63) + 2 zero pad, per point */
+#define GPN_MAX_DEPTH 8  /* trans_depth (reference configs/gpnerf_*.txt) */
+#define GPN_MAX_VIEWS 32
+#define GPN_MAX_SAMPLES 128
+
+typedef void* gpn_stream_t;
+
+int gpn_abi_version(void);
+const char* gpn_last_error(void); /* thread-local, valid until the next failing call */
+
+/* ------------------------------------------------------------------ samplers / compositing */
+
+/* sample_along_camera_ray, reference gpnerf/render_ray.py:58-102.
+ * ray_o,ray_d [R,3]; t_rand [R,S] in [0,1) or NULL (det=True); outputs pts [R,S,3], z_vals [R,S]. */
+int gpn_sample_along_ray(const float* ray_o, const float* ray_d, float near_depth, float far_depth,
+                         int R, int S, int inv_uniform, const float* t_rand, float* pts,
+                         float* z_vals, gpn_stream_t stream);
+
+/* sample_pdf, reference gpnerf/render_ray.py:9-55.  bins [R,M+1], weights [R,M] (not modified;
+ * 1e-5 is added internally), u as in gpn_sample_fine -> samples [R,N_samples]. */
+int gpn_sample_pdf(const float* bins, const float* weights, const float* u, int u_row_stride, int R,
+                   int M, int N_samples, float* samples, gpn_stream_t stream);
+
+/* sample_fine_pts + sample_pdf, reference gpnerf/render_ray.py:162-191 and :9-55.
+ * weights,z_vals [R,S] (not modified); u [R,N_imp] or, with u_row_stride==0, one row [N_imp]
+ * shared by all rays (det=True: torch.linspace(0,1,N_imp)); outputs pts [R,S+N_imp,3],
+ * z_out [R,S+N_imp] sorted ascending.  S+N_imp <= 256. */
+int gpn_sample_fine(const float* ray_o, const float* ray_d, const float* weights,
+                    const float* z_vals, const float* u, int u_row_stride, int R, int S, int N_imp,
+                    int inv_uniform, float* pts, float* z_out, gpn_stream_t stream);
+
+/* raw2outputs, reference gpnerf/render_ray.py:110-159 (model_type != 'gnt').
+ * raw [R,S,4], z_vals [R,S], vis_mask [R,S] (float 0/1) -> rgb [R,3], depth [R], weights [R,S],
+ * alpha [R,S], ray_mask [R] (float 0/1: more than 8 visible samples). */
+int gpn_raw2outputs(const float* raw, const float* z_vals, const float* vis_mask, int R, int S,
+                    int white_bkgd, float* rgb, float* depth, float* weights, float* alpha,
+                    float* ray_mask, gpn_stream_t stream);
+
+/* ------------------------------------------------------------------ projector (subsystem 1) */
+
+/* NCHW -> NHWC repack of a source-view map stack (done once per image; the reference samples NCHW
+ * maps with F.grid_sample, gpnerf/projection.py:118-129). src [V,C,H,W] -> dst [V,H,W,C]. */
+int gpn_repack_nhwc(const float* src, float* dst, int V, int C, int H, int W, gpn_stream_t stream);
+
+typedef struct {
+  const float* xyz;      /* [N,3] world points */
+  const float* proj;     /* [V,4,4] P_v = K_v . inv(c2w_v), computed on the host exactly as the
+                            reference does (projection.py:41-44) so that pixels match bit for bit */
+  const float* src_pos;  /* [V,3] source camera centres  (c2w[:3,3]) */
+  float qry_pos[3];      /* query camera centre */
+  float img_h, img_w;    /* train_cameras[0][:2]  (projection.py:109) */
+  int N, V;
+  const float* rgb;      /* [V,H,W,3]  NHWC (the API hands src_rgbs over in this layout) */
+  int rgb_h, rgb_w;
+  const float* feat;     /* [V,Hf,Wf,F] NHWC */
+  int feat_h, feat_w, feat_c;
+  const float* deep;     /* [V,Hs,Ws,D] NHWC or NULL */
+  int deep_h, deep_w, deep_c;
+  float* rgb_feat;       /* out [N,V,3+F], or NULL: geometry only, no gather */
+  float* deep_out;       /* out [N,V,D] or NULL (skipped) */
+  float* ray_diff;       /* out [N,V,4] or NULL */
+  float* mask;           /* out [N,V] float 0/1 (in front AND in bounds) or NULL */
+  float* pix;            /* out [V,N,2] clamped pixel coordinates, or NULL */
+  int32_t* taps;         /* out [V,N,2] floor() of the RGB-map sampling coordinate (x0,y0), or NULL */
+  uint8_t* front;        /* out [V,N] 1 if the point is in front of the camera, or NULL */
+} gpn_project_args_t;
+
+/* Projector.compute = compute_projections + inbound + normalize + 3x grid_sample + compute_angle,
+ * reference gpnerf/projection.py:31-139, as one fused pass. */
+int gpn_project_gather(const gpn_project_args_t* a, gpn_stream_t stream);
+
+/* ------------------------------------------------------------------ GNT (subsystem 2) */
+
+typedef struct {
+  const float* w; /* [out,in] row-major (nn.Linear.weight) */
+  const float* b; /* [out] or NULL */
+} gpn_linear_t;
+
+typedef struct {                 /* Transformer2D + Attention2D, transformer_network.py:55-122 */
+  const float *attn_norm_w, *attn_norm_b, *ff_norm_w, *ff_norm_b;
+  gpn_linear_t ff1, ff2;         /* [4C,C], [C,4C] */
+  gpn_linear_t q, k, v;          /* [C,C], no bias */
+  gpn_linear_t pos0, pos2;       /* [C/8,4], [C,C/8] */
+  gpn_linear_t attn0, attn2;     /* [C/8,C], [C,C/8] */
+  gpn_linear_t out;              /* [C,C] */
+} gpn_view_layer_t;
+
+typedef struct {                 /* Transformer + Attention('qk'), transformer_network.py:130-218 */
+  const float *attn_norm_w, *attn_norm_b, *ff_norm_w, *ff_norm_b;
+  gpn_linear_t ff1, ff2;
+  gpn_linear_t q, k, v;          /* no bias */
+  gpn_linear_t out;
+} gpn_ray_layer_t;
+
+typedef struct {                 /* GNT, transformer_network.py:221-294 (state-dict contract a10) */
+  int trans_depth;               /* <= GPN_MAX_DEPTH */
+  int in_feat_ch;                /* 32 -> rgb_feat has 3+32 channels */
+  gpn_linear_t rgbfeat0, rgbfeat2;
+  gpn_view_layer_t view[GPN_MAX_DEPTH];  /* view_crosstrans.i */
+  gpn_ray_layer_t ray[GPN_MAX_DEPTH];    /* view_selftrans.i  */
+  gpn_linear_t qfc0[GPN_MAX_DEPTH];      /* q_fcs.i.0 for even i (odd i: unused) [C,C+126] */
+  gpn_linear_t qfc2[GPN_MAX_DEPTH];      /* q_fcs.i.2 */
+  const float *norm_w, *norm_b;          /* final LayerNorm, eps 1e-5 */
+  gpn_linear_t rgb_fc;                   /* [3,C] */
+  gpn_linear_t sem_adaptor;              /* [512,512] */
+} gpn_gnt_weights_t;
+
+/* Embedder x2, transformer_network.py:6-37 and :297-306.  emb [N,GPN_EMB] =
+ * [posenc(pts) 63 | posenc(ray_d/|ray_d|) 63 | 0 0]. */
+int gpn_posenc(const float* pts, const float* ray_d, int R, int S, float* emb, gpn_stream_t stream);
+
+/* rgbfeat_fc + max over views, transformer_network.py:309-311.
+ * rgb_feat [N,V,3+F] -> feat [N,V,C], q0 [N,C]. */
+int gpn_rgbfeat(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* rgb_feat, int N,
+                int V, int in_ch, float* feat, float* q0, gpn_stream_t stream);
+
+/* Attention part of Transformer2D (attn_norm, Attention2D, residual), transformer_network.py:74-88
+ * and :107-112.  q_in [N,C], feat [N,V,C], ray_diff [N,V,4], mask [N,V] -> q_out [N,C];
+ * logits [N,V,C] = masked pre-softmax attention, stats [N,2,C] = (max_v, 1/sum_v exp) so that the
+ * per-channel view softmax of line :84 is exp(logit-max)*rsum. logits/stats may be NULL. */
+int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const float* feat,
+                  const float* ray_diff, const float* mask, int N, int V, float* q_out,
+                  float* logits, float* stats, gpn_stream_t stream);
+
+/* x + FeedForward(LayerNorm(x)), transformer_network.py:114-117 / :210-213 (eps 1e-6). x [N,C]. */
+int gpn_ff(const float* norm_w, const float* norm_b, const gpn_linear_t* fc1,
+           const gpn_linear_t* fc2, const float* x_in, int N, float* x_out, gpn_stream_t stream);
+
+/* q_fcs[i] on cat(q, pos-enc, view-enc), transformer_network.py:322-324. q [N,C], emb [N,128]. */
+int gpn_qpos(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* q_in, const float* emb,
+             int N, float* q_out, gpn_stream_t stream);
+
+/* Attention part of the ray Transformer, transformer_network.py:149-178 and :203-208.
+ * x_in [R,S,C] -> x_out [R,S,C]; abar [R,4,S] = mean over queries of A (may be NULL);
+ * weights [R,S] = head-mean of attention row 0 (transformer_network.py:216; may be NULL).
+ * S must be a multiple of 16, 16 <= S <= GPN_MAX_SAMPLES. */
+int gpn_ray_attn(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,
+                 float* abar, float* weights, gpn_stream_t stream);
+
+typedef struct {
+  int R, S, V, depth;
+  const float* logits[GPN_MAX_DEPTH]; /* per layer [N,V,C]   (from gpn_view_attn) */
+  const float* stats[GPN_MAX_DEPTH];  /* per layer [N,2,C] */
+  const float* abar[GPN_MAX_DEPTH];   /* per layer [R,4,S]   (from gpn_ray_attn) */
+  const float* mask;                  /* [N,V] */
+  /* deep-semantic source: either a materialised tensor ... */
+  const float* deep_dense;            /* [N,V,512] or NULL */
+  /* ... or the NHWC map stack, sampled on the fly with the projector's arithmetic */
+  const float* deep_map;              /* [V,Hs,Ws,512] or NULL */
+  int deep_h, deep_w;
+  const float* xyz;                   /* [N,3]   (map mode) */
+  const float* proj;                  /* [V,4,4] (map mode) */
+  float img_h, img_w;
+  float* sem3d;                       /* out [N,512] = sem_feat_3d, or NULL */
+  float* pre;                         /* out [R,512] = mean_s sum_l ray_sem_l (adaptor input) */
+} gpn_sem_args_t;
+
+/* Deep-semantic aggregation of Attention2D (:90), Attention (:180-184) and GNT.forward (:335-336)
+ * in one pass, using linearity in deep_sem. */
+int gpn_sem_aggregate(const gpn_sem_args_t* a, gpn_stream_t stream);
+
+/* Output heads, transformer_network.py:332-338 + depth expectation render_ray.py:255-256.
+ * q [R,S,C], weights [R,S], z_vals [R,S] or NULL, pre [R,512] or NULL ->
+ * out [R,3+S] = cat(rgb, weights); depth [R] (if z_vals); sem_feat [R,512] (if pre). */
+int gpn_heads(const gpn_gnt_weights_t* W, const float* q, const float* weights, const float* z_vals,
+              const float* pre, int R, int S, float* out, float* depth, float* sem_feat,
+              gpn_stream_t stream);
+
+/* Whole GNT.forward (transformer_network.py:295-338) on a caller-provided workspace.
+ * Inputs as gpn_rgbfeat / gpn_view_attn; `sem` carries the deep-semantic source and outputs
+ * (its logits/stats/abar/mask/R/S/V/depth fields are filled in by this call); sem may be NULL. */
+size_t gpn_gnt_workspace_bytes(int R, int S, int V, int depth);
+int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat, const float* ray_diff,
+                    const float* mask, const float* pts, const float* ray_d, const float* z_vals,
+                    int R, int S, int V, gpn_sem_args_t* sem, float* out, float* depth,
+                    float* sem_feat, void* workspace, size_t workspace_bytes, gpn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPNERF_HIP_H */

@@ -1,0 +1,307 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against the CPU oracle on the
+same seeded inputs and against the golden vectors produced by the reference itself.
+
+Bars (BASELINE.json north_star): projection masks, pixel coordinates and bilinear tap indices
+bit-exact; gathered values bit-exact (same fmaf chain as torch CPU); rgb / depth / weights /
+semantic features within 1e-4 relative to the tensor scale (fp32).
+"""
+import ctypes as C
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # north_star: "rgb/depth/logits within 1e-4 relative (fp32)"
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def net(dev):
+    from gp_nerf_amd.transformer_network import GNT
+    args = types.SimpleNamespace(netwidth=64, trans_depth=8, save_feature=False,
+                                 semantic_model="fpn", num_classes=20)
+    n = GNT(args, in_feat_ch=32, posenc_dim=63, viewenc_dim=63, ret_alpha=True)
+    n.load_state_dict(cases.weights(), strict=True)
+    return n.to(dev).eval()
+
+
+def rel(a, b):
+    """max |a-b| relative to the scale of b (at least 1)."""
+    a = a.detach().float().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().float().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.isfinite(a).all(), "non-finite values in the HIP result"
+    return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+
+
+def to(dev, d):
+    return {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in d.items()}
+
+
+# ------------------------------------------------------------------------------ projector
+def test_projector_bit_exact(dev, golden):
+    from gp_nerf_amd.projection import Projector
+    g = golden("g1_projector")
+    c = cases.g1_projector()
+    cd = to(dev, c)
+    P = Projector(dev)
+    rgb_feat, deep, ray_diff, mask = P.compute(cd["pts"], cd["camera"], cd["src_rgbs"],
+                                               cd["src_cameras"], cd["featmaps"],
+                                               cd["deep_semantics"])
+    pix, front = P.compute_projections(cd["pts"], cd["src_cameras"][0])
+    # vs the oracle run on this machine
+    o_rgb, o_deep, o_rd, o_mask, o_pix = oracle.projector.compute(
+        c["pts"], c["camera"], c["src_rgbs"], c["src_cameras"], c["featmaps"],
+        c["deep_semantics"], return_pix=True)
+    _, o_front = oracle.projector.compute_projections(c["pts"], c["src_cameras"][0])
+    report = {}
+    for name, got, want in (("pix", pix, o_pix), ("front", front, o_front), ("mask", mask, o_mask),
+                            ("rgb_feat", rgb_feat, o_rgb), ("deep", deep, o_deep)):
+        report[name] = int((got.cpu() != want).sum())
+    assert all(v == 0 for v in report.values()), "bit mismatches vs oracle: %s" % report
+    assert rel(ray_diff, o_rd) < 1e-5
+    # vs the golden vectors written by the reference itself
+    assert np.array_equal(pix.cpu().numpy(), g["pix"])
+    assert np.array_equal(front.cpu().numpy(), g["in_front"])
+    assert np.array_equal(mask.cpu().numpy(), g["mask"])
+    assert np.array_equal(rgb_feat.cpu().numpy(), g["rgb_feat"])
+    assert np.array_equal(deep[:8].cpu().numpy(), g["deep_head"])
+    assert rel(ray_diff, g["ray_diff"]) < 1e-5
+
+
+def test_projector_taps_and_helpers(dev):
+    from gp_nerf_amd.projection import Projector
+    c = cases.g1_projector()
+    cd = to(dev, c)
+    P = Projector(dev)
+    sv = P.prepare(cd["camera"], cd["src_rgbs"], cd["src_cameras"], cd["featmaps"], None)
+    out = P._launch(cd["pts"], sv, True, False, want_pix=True)
+    pix_o, _ = oracle.projector.compute_projections(c["pts"], c["src_cameras"][0])
+    taps_o = oracle.projector.tap_indices(pix_o, float(c["H"]), float(c["W"]), c["H"], c["W"])
+    assert torch.equal(out["taps"].cpu(), taps_o), "bilinear tap indices differ"
+    h, w = float(c["H"]), float(c["W"])
+    assert torch.equal(P.inbound(out["pix"], h, w).cpu(), oracle.projector.inbound(pix_o, h, w))
+    assert torch.equal(P.normalize(out["pix"], h, w).cpu(), oracle.projector.normalize(pix_o, h, w))
+    ang = P.compute_angle(cd["pts"], cd["camera"][0], cd["src_cameras"][0])
+    assert rel(ang, oracle.projector.compute_angle(c["pts"], c["camera"][0], c["src_cameras"][0])) < 1e-5
+    # fused path == full path on the shared outputs
+    a = P.compute_fused(cd["pts"], sv)
+    b = P.compute(cd["pts"], cd["camera"], cd["src_rgbs"], cd["src_cameras"], cd["featmaps"], None)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[3]) and b[1] is None
+
+
+def test_projector_ragged_and_empty(dev):
+    from gp_nerf_amd.projection import Projector
+    c = cases.g1_projector()
+    cd = to(dev, c)
+    P = Projector(dev)
+    for R in (0, 1, 3, 37):
+        pts = cd["pts"][:R, :5].contiguous()
+        got = P.compute(pts, cd["camera"], cd["src_rgbs"], cd["src_cameras"], cd["featmaps"],
+                        cd["deep_semantics"])
+        want = oracle.projector.compute(c["pts"][:R, :5], c["camera"], c["src_rgbs"],
+                                        c["src_cameras"], c["featmaps"], c["deep_semantics"])
+        for gt, wt, nm in zip(got, want, ("rgb_feat", "deep", "ray_diff", "mask")):
+            assert tuple(gt.shape) == tuple(wt.shape), nm
+            if R and nm != "ray_diff":
+                assert torch.equal(gt.cpu(), wt), "%s R=%d" % (nm, R)
+    with pytest.raises(RuntimeError):
+        P.compute(c["pts"], c["camera"], c["src_rgbs"], c["src_cameras"], c["featmaps"], None)
+
+
+# ------------------------------------------------------------------------------ samplers
+def test_samplers(dev, golden):
+    from gp_nerf_amd import render_ray as rr
+    g = golden("g3_samplers")
+    c = cases.g3_samplers()
+    cd = to(dev, c)
+    for inv, tag in ((False, "lin"), (True, "inv")):
+        pts, z = rr.sample_along_camera_ray(cd["ray_o"], cd["ray_d"], cd["depth_range"], 48,
+                                            inv_uniform=inv, det=True)
+        assert np.array_equal(z.cpu().numpy(), g["z_" + tag]), "coarse depths must be bit-exact"
+        assert np.array_equal(pts.cpu().numpy(), g["pts_" + tag])
+        w0 = cd["weights"].clone()
+        fpts, fz = rr.sample_fine_pts(inv, 16, True, 48, cd, cd["weights"], z)
+        assert torch.equal(w0, cd["weights"]), "caller weights were mutated"
+        assert rel(fz, g["fz_" + tag]) < 1e-5 and rel(fpts, g["fpts_" + tag]) < 1e-5
+        assert bool((fz[:, 1:] >= fz[:, :-1]).all()), "fine depths must be sorted"
+    # stochastic paths: same formulas with injected randoms
+    torch.manual_seed(3)
+    pts, z = rr.sample_along_camera_ray(cd["ray_o"], cd["ray_d"], cd["depth_range"], 48,
+                                        inv_uniform=True, det=False)
+    _, zd = oracle.sampling.sample_along_camera_ray(c["ray_o"], c["ray_d"], c["depth_range"], 48,
+                                                    inv_uniform=True, det=True)
+    mids = 0.5 * (zd[:, 1:] + zd[:, :-1])
+    lo = torch.cat([zd[:, :1], mids], -1)
+    hi = torch.cat([mids, zd[:, -1:]], -1)
+    zc = z.cpu()
+    assert bool(((zc >= torch.minimum(lo, hi) - 1e-6) & (zc <= torch.maximum(lo, hi) + 1e-6)).all())
+    # sample_pdf entry point
+    bins = torch.sort(torch.rand(7, 12), dim=-1)[0]
+    wts = torch.rand(7, 11)
+    got = rr.sample_pdf(bins.to(dev), wts.to(dev), 9, det=True)
+    assert rel(got, oracle.sampling.sample_pdf(bins, wts, 9, det=True)) < 1e-5
+    # raw2outputs
+    zl = torch.from_numpy(g["z_lin"]).to(dev)
+    for white in (False, True):
+        r = rr.raw2outputs(cd["raw"], zl, cd["vis_mask"], white_bkgd=white)
+        o = oracle.sampling.raw2outputs(c["raw"], zl.cpu(), c["vis_mask"], white_bkgd=white)
+        for k in ("rgb", "depth", "weights", "alpha"):
+            assert rel(r[k], o[k]) < 1e-5, k
+        assert torch.equal(r["mask"].cpu(), o["mask"])
+
+
+# ------------------------------------------------------------------------------ GNT stage by stage
+def _stage_inputs(S, R=8):
+    c = cases.g2_gnt(S, R=R)
+    rec = {}
+    sd = cases.weights()
+    out = oracle.gnt.forward(sd, c["rgb_feat"], c["deep_sem"], c["ray_diff"], c["mask"], c["pts"],
+                             c["ray_d"], intermediates=rec)
+    return c, rec, out
+
+
+@pytest.mark.parametrize("S", [48, 64])
+def test_gnt_stages(dev, net, S):
+    from gp_nerf_amd import _lib
+    L = _lib.lib()
+    c, rec, _ = _stage_inputs(S)
+    R, V = c["rgb_feat"].shape[0], c["rgb_feat"].shape[2]
+    N = R * S
+    W = net._weights()
+    st = _lib.stream()
+    f = lambda t: t.to(dev).float().contiguous()
+    e = lambda *s: torch.empty(s, device=dev)
+    errs = {}
+    # posenc
+    emb = e(N, 128)
+    _lib.check(L.gpn_posenc(_lib.ptr(f(c["pts"])), _lib.ptr(f(c["ray_d"])), R, S, _lib.ptr(emb), st), "posenc")
+    want = torch.cat([rec["pos_enc"].reshape(N, 63),
+                      rec["view_enc"][:, None].expand(R, S, 63).reshape(N, 63),
+                      torch.zeros(N, 2)], -1)
+    errs["posenc"] = rel(emb, want)
+    # rgbfeat
+    feat, q0 = e(N, V, 64), e(N, 64)
+    _lib.check(L.gpn_rgbfeat(C.byref(W.rgbfeat0), C.byref(W.rgbfeat2), _lib.ptr(f(c["rgb_feat"])), N, V,
+                             35, _lib.ptr(feat), _lib.ptr(q0), st), "rgbfeat")
+    errs["feat"] = rel(feat, rec["feat"].reshape(N, V, 64))
+    errs["q0"] = rel(q0, rec["q0"].reshape(N, 64))
+    rd, mk = f(c["ray_diff"]), f(c["mask"])
+    feat_ref = f(rec["feat"].reshape(N, V, 64))
+    emb_ref = f(want)
+    for l in (0, 1, 7):
+        q_in = f((rec["q0"] if l == 0 else rec["q_ray"][l - 1]).reshape(N, 64))
+        qo, lg, stt = e(N, 64), e(N, V, 64), e(N, 2, 64)
+        _lib.check(L.gpn_view_attn(C.byref(W.view[l]), _lib.ptr(q_in), _lib.ptr(feat_ref), _lib.ptr(rd),
+                                   _lib.ptr(mk), N, V, _lib.ptr(qo), _lib.ptr(lg), _lib.ptr(stt), st), "view")
+        errs["view_attn%d" % l] = rel(qo, rec["q_view_attn"][l].reshape(N, 64))
+        attn = torch.exp(lg - stt[:, 0][:, None]) * stt[:, 1][:, None]
+        errs["attn2d%d" % l] = rel(attn, rec["attn2d"][l].reshape(N, V, 64))
+        vl = W.view[l]
+        q2 = e(N, 64)
+        _lib.check(L.gpn_ff(vl.ff_norm_w, vl.ff_norm_b, C.byref(vl.ff1), C.byref(vl.ff2),
+                            _lib.ptr(f(rec["q_view_attn"][l].reshape(N, 64))), N, _lib.ptr(q2), st), "ff")
+        errs["view_ff%d" % l] = rel(q2, rec["q_view"][l].reshape(N, 64))
+        if l % 2 == 0:
+            q3 = e(N, 64)
+            _lib.check(L.gpn_qpos(C.byref(W.qfc0[l]), C.byref(W.qfc2[l]),
+                                  _lib.ptr(f(rec["q_view"][l].reshape(N, 64))), _lib.ptr(emb_ref), N,
+                                  _lib.ptr(q3), st), "qpos")
+            errs["qpos%d" % l] = rel(q3, rec["q_pos"][l // 2].reshape(N, 64))
+            x_in = rec["q_pos"][l // 2]
+        else:
+            x_in = rec["q_view"][l]
+        xo, ab, wt = e(R, S, 64), e(R, 4, S), e(R, S)
+        _lib.check(L.gpn_ray_attn(C.byref(W.ray[l]), _lib.ptr(f(x_in)), R, S, _lib.ptr(xo), _lib.ptr(ab),
+                                  _lib.ptr(wt), st), "ray")
+        errs["ray_attn%d" % l] = rel(xo, rec["q_ray_attn"][l])
+        errs["abar%d" % l] = rel(ab, rec["A"][l].mean(dim=2))
+        errs["weights%d" % l] = rel(wt, rec["A"][l].mean(dim=1)[:, 0])
+    torch.cuda.synchronize()
+    bad = {k: v for k, v in errs.items() if not v < 2e-5}
+    assert not bad, "stage errors above 2e-5: %s (all: %s)" % (bad, errs)
+
+
+@pytest.mark.parametrize("S", [48, 64])
+def test_gnt_forward_vs_golden(dev, net, golden, S):
+    g = golden("g2_gnt_s%d" % S)
+    c = cases.g2_gnt(S)
+    cd = to(dev, c)
+    out, sem, sem3d = net(cd["rgb_feat"], cd["deep_sem"], cd["ray_diff"], cd["mask"], cd["pts"],
+                          cd["ray_d"])
+    errs = {"out": rel(out, g["out"]), "sem": rel(sem, g["sem"])}
+    if S == 48:
+        errs["sem3d"] = rel(sem3d, g["sem3d"])
+    else:
+        errs["sem3d_sum"] = rel(sem3d.double().sum(-1), g["sem3d_sum"])
+    assert max(errs.values()) < TOL, errs
+    assert rel(out[:, 3:].sum(-1), np.ones(out.shape[0], np.float32)) < 1e-5  # weights sum to 1
+    # odd ray count (second ray slot of the last workgroup empty) and determinism
+    out2, sem2, _ = net(cd["rgb_feat"][:5], cd["deep_sem"][:5], cd["ray_diff"][:5], cd["mask"][:5],
+                        cd["pts"][:5], cd["ray_d"][:5])
+    assert torch.equal(out2, out[:5]) and torch.equal(sem2, sem[:5]), "results depend on batch size"
+
+
+# ------------------------------------------------------------------------------ render_rays / image
+def _model(net):
+    return types.SimpleNamespace(net_coarse=net, net_fine=None)
+
+
+def test_render_rays_vs_golden(dev, net, golden):
+    from gp_nerf_amd.projection import Projector
+    from gp_nerf_amd.render_ray import render_rays
+    g = golden("g4_render_rays")
+    c = cases.g4_render_rays()
+    rb = to(dev, c["ray_batch"])
+    ret = render_rays(rb, _model(net), c["featmaps"].to(dev), c["deep_semantics"].to(dev),
+                      Projector(dev), N_samples=48, inv_uniform=True, N_importance=16, det=True,
+                      ret_alpha=True, single_net=True)
+    errs = {}
+    for lvl, t in (("outputs_coarse", "coarse"), ("outputs_fine", "fine")):
+        o = ret[lvl]
+        errs[t + "_rgb"] = rel(o["rgb"], g[t + "_rgb"])
+        errs[t + "_weights"] = rel(o["weights"], g[t + "_weights"])
+        errs[t + "_depth"] = rel(o["depth"], g[t + "_depth"])
+        errs[t + "_feats_out"] = rel(o["feats_out"], g[t + "_feats_out"])
+        errs[t + "_f3d"] = rel(o["feats_out_3d"][:4], g[t + "_f3d_head"])
+        errs[t + "_f3d_sum"] = rel(o["feats_out_3d"].double().sum(-1), g[t + "_f3d_sum"])
+    assert max(errs.values()) < TOL, errs
+
+
+def test_render_single_image_vs_golden(dev, net, golden):
+    from gp_nerf_amd.projection import Projector
+    from gp_nerf_amd.render_image import render_single_image
+    g = golden("g5_render_image")
+    c = cases.g5_render_image()
+    rb = to(dev, c["ray_batch"])
+    sampler = types.SimpleNamespace(H=c["H"], W=c["W"])
+    outs = []
+    for chunk in (50, 768):
+        outs.append(render_single_image(sampler, rb, _model(net), Projector(dev), chunk,
+                                        N_samples=16, inv_uniform=True, N_importance=8, det=True,
+                                        render_stride=1, featmaps=c["featmaps"].to(dev),
+                                        deep_semantics=c["deep_semantics"].to(dev), ret_alpha=True,
+                                        single_net=True))
+    errs = {}
+    for lvl, t in (("outputs_coarse", "coarse"), ("outputs_fine", "fine")):
+        for k in ("rgb", "depth", "weights", "feats_out"):
+            a, b = outs[0][lvl][k], outs[1][lvl][k]
+            assert not b.is_cuda and tuple(b.shape) == g[t + "_" + k].shape
+            errs[t + "_" + k] = rel(b, g[t + "_" + k])
+            assert torch.equal(a, b), "result depends on chunk_size (%s %s)" % (lvl, k)
+        f3 = outs[1][lvl]["feats_out_3d"]
+        assert tuple(f3.shape) == tuple(g[t + "_f3d_shape"])
+        errs[t + "_f3d_sum"] = rel(f3.double().reshape(c["H"], c["W"], -1, 512).sum(-1),
+                                   g[t + "_f3d_sum"])
+    assert max(errs.values()) < TOL, errs

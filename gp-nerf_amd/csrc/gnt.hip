@@ -387,19 +387,21 @@ k_qpos(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ q_in,
 template <int NT>
 struct RayCfg {
   static constexpr int RPW = NT <= 4 ? 2 : 1;
-  static constexpr int S = NT * 16;
-  static constexpr int LDV = S + 4;
+  static constexpr int SP = NT * 16;  // samples per ray, padded to whole 16-sample tiles
+  static constexpr int LDV = SP + 4;
   static constexpr int THREADS = RPW * NT * 64;
   static constexpr int LDS_FLOATS =
-      4 * 64 * LDW + 3 * 64 + RPW * S * LDW + RPW * 64 * LDV + RPW * NT * 4 * S;
+      4 * 64 * LDW + 3 * 64 + RPW * SP * LDW + RPW * 64 * LDV + RPW * NT * 4 * SP;
 };
 
 template <int NT>
 __global__ void __launch_bounds__(RayCfg<NT>::THREADS)
-k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, float* __restrict__ x_out,
-           float* __restrict__ abar, float* __restrict__ weights) {
+k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
+           float* __restrict__ x_out, float* __restrict__ abar, float* __restrict__ weights) {
+  // S (<= SP) real samples per ray; keys >= S are masked out of the softmax, queries >= S are
+  // computed on clamped data and never stored.
   using Cfg = RayCfg<NT>;
-  constexpr int S = Cfg::S, RPW = Cfg::RPW, LDV = Cfg::LDV, NTHR = Cfg::THREADS;
+  constexpr int SP = Cfg::SP, RPW = Cfg::RPW, LDV = Cfg::LDV, NTHR = Cfg::THREADS;
   float* Wq = smem;
   float* Wk = Wq + 64 * LDW;
   float* Wv = Wk + 64 * LDW;
@@ -408,7 +410,7 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, float* __r
   float* gam = bO + 64;
   float* bet = gam + 64;
   float* Ks = bet + 64;
-  float* Vt = Ks + RPW * S * LDW;
+  float* Vt = Ks + RPW * SP * LDW;
   float* part = Vt + RPW * 64 * LDV;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   stage_matrix(Wq, LDW, Lw.q.w, 64, 64, tid, NTHR);
@@ -421,14 +423,18 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, float* __r
   __syncthreads();
   const int j = lane & 15, g = lane >> 4;
   const int slot = wave / NT, t = wave - slot * NT;
-  float* Ks_s = Ks + slot * S * LDW;
+  float* Ks_s = Ks + slot * SP * LDW;
   float* Vt_s = Vt + slot * 64 * LDV;
+  const int sq = 16 * t + j;          // this lane's query / sample index
+  const bool qvalid = sq < S;
+  const int sqc = qvalid ? sq : S - 1;
+  const float qsel = qvalid ? 1.0f : 0.0f;
 
   for (int grp = blockIdx.x; grp * RPW < R; grp += gridDim.x) {
     const int ray = grp * RPW + slot;
     const bool valid = ray < R;
     const int rc = valid ? ray : R - 1;
-    const size_t row = ((size_t)rc * S + 16 * t + j) * C64;
+    const size_t row = ((size_t)rc * S + sqc) * C64;
     f4 x[4], xn[4], qT[4];
 #pragma unroll
     for (int T = 0; T < 4; ++T) x[T] = ld4(x_in + row + 16 * T + 4 * g);
@@ -477,6 +483,11 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, float* __r
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
         sT[kt] = sT[kt] * f4_splat(0.25f);
+        if (kt == NT - 1) {  // only the last key tile can hold padding keys
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (16 * kt + 4 * g + r >= S) sT[kt][r] = -INFINITY;
+        }
         mx = fmaxf(mx, fmaxf(fmaxf(sT[kt].x, sT[kt].y), fmaxf(sT[kt].z, sT[kt].w)));
       }
       mx = max_over_g(mx);
@@ -496,12 +507,12 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, float* __r
         if (t == 0) wacc[kt] = wacc[kt] + sT[kt];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float c = sT[kt][r];
+          float c = sT[kt][r] * qsel;
           c += __shfl_xor(c, 1);
           c += __shfl_xor(c, 2);
           c += __shfl_xor(c, 4);
           c += __shfl_xor(c, 8);
-          if (j == 0) part[((slot * NT + t) * 4 + h) * S + 16 * kt + 4 * g + r] = c;
+          if (j == 0) part[((slot * NT + t) * 4 + h) * SP + 16 * kt + 4 * g + r] = c;
         }
       }
       // O^T[h] = V_h^T . P^T : A = V (channels of head h on rows), B = P^T (keys in registers)
@@ -522,24 +533,31 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, float* __r
     for (int M = 0; M < 4; ++M) y[M] = ld4(bO + 16 * M + 4 * g);
     lin_T<4, 4>(Wo, LDW, oT, y, lane);
     if (valid) {
-      const size_t orow = ((size_t)ray * S + 16 * t + j) * C64;
+      if (qvalid) {
+        const size_t orow = ((size_t)ray * S + sq) * C64;
 #pragma unroll
-      for (int M = 0; M < 4; ++M) st4(x_out + orow + 16 * M + 4 * g, y[M] + x[M]);
+        for (int M = 0; M < 4; ++M) st4(x_out + orow + 16 * M + 4 * g, y[M] + x[M]);
+      }
       if (weights != nullptr && t == 0 && j == 0) {  // head-mean of attention row 0 (:216)
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
-          st4(weights + (size_t)ray * S + 16 * kt + 4 * g, wacc[kt] * f4_splat(0.25f));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = 16 * kt + 4 * g + r;
+            if (key < S) weights[(size_t)ray * S + key] = wacc[kt][r] * 0.25f;
+          }
       }
     }
     __syncthreads();
     if (abar != nullptr) {
-      for (int idx = tid; idx < RPW * 4 * S; idx += NTHR) {
-        const int sl = idx / (4 * S), rem = idx - sl * 4 * S;  // rem = h*S + key
+      for (int idx = tid; idx < RPW * 4 * SP; idx += NTHR) {
+        const int sl = idx / (4 * SP), rem = idx - sl * 4 * SP;
+        const int h = rem / SP, key = rem - h * SP;
         const int rr = grp * RPW + sl;
         float c = 0.f;
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) c += part[(sl * NT + tt) * 4 * S + rem];
-        if (rr < R) abar[(size_t)rr * 4 * S + rem] = c * (1.0f / S);
+        for (int tt = 0; tt < NT; ++tt) c += part[(sl * NT + tt) * 4 * SP + rem];
+        if (rr < R && key < S) abar[((size_t)rr * 4 + h) * S + key] = c / (float)S;
       }
     }
     __syncthreads();
@@ -696,6 +714,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 extern "C" int gpn_posenc(const float* pts, const float* ray_d, int R, int S, float* emb,
                           gpn_stream_t stream) {
+  if (R == 0) return GPN_OK;  // empty batch (pointers may be null)
   GPN_REQUIRE(pts && ray_d && emb, "gpn_posenc: null pointer");
   GPN_REQUIRE(R >= 0 && S >= 1, "gpn_posenc: bad shape");
   const long long N = (long long)R * S;
@@ -708,6 +727,7 @@ extern "C" int gpn_posenc(const float* pts, const float* ray_d, int R, int S, fl
 
 extern "C" int gpn_rgbfeat(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* rgb_feat,
                            int N, int V, int in_ch, float* feat, float* q0, gpn_stream_t stream) {
+  if (N == 0) return GPN_OK;  // empty batch (pointers may be null)
   GPN_REQUIRE(fc0 && fc2 && rgb_feat && feat && q0, "gpn_rgbfeat: null pointer");
   REQ_LIN(*fc2, "gpn_rgbfeat.fc2");
   GPN_REQUIRE(fc0->w, "gpn_rgbfeat: null weight");
@@ -726,6 +746,7 @@ extern "C" int gpn_rgbfeat(const gpn_linear_t* fc0, const gpn_linear_t* fc2, con
 extern "C" int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const float* feat,
                              const float* ray_diff, const float* mask, int N, int V, float* q_out,
                              float* logits, float* stats, gpn_stream_t stream) {
+  if (N == 0) return GPN_OK;  // empty batch (pointers may be null)
   GPN_REQUIRE(L && q_in && feat && ray_diff && mask && q_out, "gpn_view_attn: null pointer");
   REQ_LIN(L->q, "gpn_view_attn.q");
   REQ_LIN(L->k, "gpn_view_attn.k");
@@ -751,6 +772,7 @@ extern "C" int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const
 extern "C" int gpn_ff(const float* norm_w, const float* norm_b, const gpn_linear_t* fc1,
                       const gpn_linear_t* fc2, const float* x_in, int N, float* x_out,
                       gpn_stream_t stream) {
+  if (N == 0) return GPN_OK;  // empty batch (pointers may be null)
   GPN_REQUIRE(norm_w && norm_b && fc1 && fc2 && x_in && x_out, "gpn_ff: null pointer");
   REQ_LIN(*fc1, "gpn_ff.fc1");
   REQ_LIN(*fc2, "gpn_ff.fc2");
@@ -769,6 +791,7 @@ extern "C" int gpn_ff(const float* norm_w, const float* norm_b, const gpn_linear
 
 extern "C" int gpn_qpos(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* q_in,
                         const float* emb, int N, float* q_out, gpn_stream_t stream) {
+  if (N == 0) return GPN_OK;  // empty batch (pointers may be null)
   GPN_REQUIRE(fc0 && fc2 && q_in && emb && q_out, "gpn_qpos: null pointer");
   GPN_REQUIRE(fc0->w, "gpn_qpos: null weight");
   REQ_LIN(*fc2, "gpn_qpos.fc2");
@@ -787,48 +810,48 @@ extern "C" int gpn_qpos(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const 
 }
 
 template <int NT>
-static int launch_ray_attn(const gpn_ray_layer_t* L, const float* x_in, int R, float* x_out,
+static int launch_ray_attn(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,
                            float* abar, float* weights, hipStream_t stream) {
   using Cfg = RayCfg<NT>;
   const size_t lds = sizeof(float) * Cfg::LDS_FLOATS;
   int rc = set_lds_limit(reinterpret_cast<const void*>(k_ray_attn<NT>), lds);
   if (rc) return rc;
   const int grid = persistent_grid(((long long)R + Cfg::RPW - 1) / Cfg::RPW);
-  hipLaunchKernelGGL(k_ray_attn<NT>, dim3(grid), dim3(Cfg::THREADS), lds, stream, *L, x_in, R, x_out,
-                     abar, weights);
+  hipLaunchKernelGGL(k_ray_attn<NT>, dim3(grid), dim3(Cfg::THREADS), lds, stream, *L, x_in, R, S,
+                     x_out, abar, weights);
   GPN_LAUNCH_CHECK("k_ray_attn");
   return GPN_OK;
 }
 
 extern "C" int gpn_ray_attn(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,
                             float* abar, float* weights, gpn_stream_t stream) {
+  if (R == 0) return GPN_OK;  // empty batch (pointers may be null)
   GPN_REQUIRE(L && x_in && x_out, "gpn_ray_attn: null pointer");
   REQ_LIN(L->q, "gpn_ray_attn.q");
   REQ_LIN(L->k, "gpn_ray_attn.k");
   REQ_LIN(L->v, "gpn_ray_attn.v");
   REQ_LIN(L->out, "gpn_ray_attn.out");
   GPN_REQUIRE(L->attn_norm_w && L->attn_norm_b, "gpn_ray_attn: null weight");
-  GPN_REQUIRE(R >= 0 && S >= 16 && S <= GPN_MAX_SAMPLES && S % 16 == 0,
-              "gpn_ray_attn: samples per ray must be a multiple of 16 in [16,%d] (got %d)",
-              GPN_MAX_SAMPLES, S);
-  GPN_REQUIRE(aligned16(x_in) && aligned16(x_out) && aligned16(weights),
-              "gpn_ray_attn: tensors must be 16-byte aligned");
+  GPN_REQUIRE(R >= 0 && S >= 1 && S <= GPN_MAX_SAMPLES,
+              "gpn_ray_attn: samples per ray must be in [1,%d] (got %d)", GPN_MAX_SAMPLES, S);
+  GPN_REQUIRE(aligned16(x_in) && aligned16(x_out), "gpn_ray_attn: tensors must be 16-byte aligned");
   if (R == 0) return GPN_OK;
   hipStream_t st = (hipStream_t)stream;
-  switch (S / 16) {
-    case 1: return launch_ray_attn<1>(L, x_in, R, x_out, abar, weights, st);
-    case 2: return launch_ray_attn<2>(L, x_in, R, x_out, abar, weights, st);
-    case 3: return launch_ray_attn<3>(L, x_in, R, x_out, abar, weights, st);
-    case 4: return launch_ray_attn<4>(L, x_in, R, x_out, abar, weights, st);
-    case 5: return launch_ray_attn<5>(L, x_in, R, x_out, abar, weights, st);
-    case 6: return launch_ray_attn<6>(L, x_in, R, x_out, abar, weights, st);
-    case 7: return launch_ray_attn<7>(L, x_in, R, x_out, abar, weights, st);
-    default: return launch_ray_attn<8>(L, x_in, R, x_out, abar, weights, st);
+  switch ((S + 15) / 16) {
+    case 1: return launch_ray_attn<1>(L, x_in, R, S, x_out, abar, weights, st);
+    case 2: return launch_ray_attn<2>(L, x_in, R, S, x_out, abar, weights, st);
+    case 3: return launch_ray_attn<3>(L, x_in, R, S, x_out, abar, weights, st);
+    case 4: return launch_ray_attn<4>(L, x_in, R, S, x_out, abar, weights, st);
+    case 5: return launch_ray_attn<5>(L, x_in, R, S, x_out, abar, weights, st);
+    case 6: return launch_ray_attn<6>(L, x_in, R, S, x_out, abar, weights, st);
+    case 7: return launch_ray_attn<7>(L, x_in, R, S, x_out, abar, weights, st);
+    default: return launch_ray_attn<8>(L, x_in, R, S, x_out, abar, weights, st);
   }
 }
 
 extern "C" int gpn_sem_aggregate(const gpn_sem_args_t* a, gpn_stream_t stream) {
   GPN_REQUIRE(a, "gpn_sem_aggregate: null args");
+  if (a->R == 0) return GPN_OK;  // empty batch
   GPN_REQUIRE(a->R >= 0 && a->S >= 1 && a->V >= 1 && a->V <= GPN_MAX_VIEWS && a->depth >= 1 &&
                   a->depth <= GPN_MAX_DEPTH, "gpn_sem_aggregate: bad shape");
   GPN_REQUIRE(a->mask && a->pre, "gpn_sem_aggregate: null pointer");
@@ -853,6 +876,7 @@ extern "C" int gpn_sem_aggregate(const gpn_sem_args_t* a, gpn_stream_t stream) {
 extern "C" int gpn_heads(const gpn_gnt_weights_t* W, const float* q, const float* weights,
                          const float* z_vals, const float* pre, int R, int S, float* out,
                          float* depth, float* sem_feat, gpn_stream_t stream) {
+  if (R == 0) return GPN_OK;  // empty batch (pointers may be null)
   GPN_REQUIRE(W && q && weights && out, "gpn_heads: null pointer");
   GPN_REQUIRE(W->norm_w && W->norm_b && W->rgb_fc.w, "gpn_heads: null weight");
   GPN_REQUIRE(R >= 0 && S >= 1, "gpn_heads: bad shape");
@@ -903,13 +927,14 @@ extern "C" int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat
                                const float* ray_d, const float* z_vals, int R, int S, int V,
                                gpn_sem_args_t* sem, float* out, float* depth, float* sem_feat,
                                void* workspace, size_t workspace_bytes, gpn_stream_t stream) {
+  if (R == 0) return GPN_OK;  // empty batch (pointers may be null)
   GPN_REQUIRE(W && rgb_feat && ray_diff && mask && pts && ray_d && out && workspace,
               "gpn_gnt_forward: null pointer");
   const int D = W->trans_depth;
   GPN_REQUIRE(D >= 1 && D <= GPN_MAX_DEPTH, "gpn_gnt_forward: trans_depth must be in [1,%d]",
               GPN_MAX_DEPTH);
-  GPN_REQUIRE(R >= 0 && S >= 16 && S % 16 == 0 && S <= GPN_MAX_SAMPLES && V >= 1 &&
-                  V <= GPN_MAX_VIEWS, "gpn_gnt_forward: unsupported shape R=%d S=%d V=%d", R, S, V);
+  GPN_REQUIRE(R >= 0 && S >= 1 && S <= GPN_MAX_SAMPLES && V >= 1 && V <= GPN_MAX_VIEWS,
+              "gpn_gnt_forward: unsupported shape R=%d S=%d V=%d", R, S, V);
   const GntWs L = gnt_ws_layout(R, S, V, D);
   GPN_REQUIRE(workspace_bytes >= L.total, "gpn_gnt_forward: workspace too small (%zu < %zu)",
               workspace_bytes, L.total);

@@ -182,6 +182,7 @@ extern "C" int gpn_repack_nhwc(const float* src, float* dst, int V, int C, int H
 
 extern "C" int gpn_project_gather(const gpn_project_args_t* a, gpn_stream_t stream) {
   GPN_REQUIRE(a, "gpn_project_gather: null args");
+  if (a->N == 0) return GPN_OK;  // empty batch: nothing to validate or launch (pointers may be null)
   GPN_REQUIRE(a->xyz && a->proj && a->src_pos, "gpn_project_gather: null pointer");
   GPN_REQUIRE(a->N >= 0 && a->V >= 1 && a->V <= GPN_MAX_VIEWS,
               "gpn_project_gather: need 1 <= V <= %d (got %d)", GPN_MAX_VIEWS, a->V);
@@ -200,7 +201,6 @@ extern "C" int gpn_project_gather(const gpn_project_args_t* a, gpn_stream_t stre
                 "gpn_project_gather: deep-semantic maps must have %d channels (got %d)", GPN_SEM,
                 a->deep_c);
   }
-  if (a->N == 0) return GPN_OK;
   const long long n_pairs = (long long)a->N * a->V;
   const int cus = gpn_num_cus();
   {

@@ -39,8 +39,10 @@ __global__ void k_sample_along_ray(const float* __restrict__ ray_o, const float*
 // torch.cumsum.  Ends with a barrier.
 __device__ __forceinline__ void build_cdf(const float* ww, float* cdf, int M, int lane) {
   if (lane == 0) {
-    float total = 0.0f;
-    for (int i = 0; i < M; ++i) total += ww[i];
+    // torch.sum is a cascade (near-exact) reduction: accumulate in fp64 and round once
+    double acc = 0.0;
+    for (int i = 0; i < M; ++i) acc += (double)ww[i];
+    const float total = (float)acc;
     float c = 0.0f;
     cdf[0] = 0.0f;
     for (int i = 0; i < M; ++i) {
@@ -178,6 +180,7 @@ extern "C" int gpn_sample_along_ray(const float* ray_o, const float* ray_d, floa
                                     float far_depth, int R, int S, int inv_uniform,
                                     const float* t_rand, float* pts, float* z_vals,
                                     gpn_stream_t stream) {
+  if (R == 0) return GPN_OK;  // empty batch (pointers may be null)
   GPN_REQUIRE(ray_o && ray_d && pts && z_vals, "gpn_sample_along_ray: null pointer");
   GPN_REQUIRE(R >= 0 && S >= 2, "gpn_sample_along_ray: need R>=0, S>=2 (got R=%d S=%d)", R, S);
   GPN_REQUIRE(near_depth > 0 && far_depth > near_depth,
@@ -195,6 +198,7 @@ extern "C" int gpn_sample_fine(const float* ray_o, const float* ray_d, const flo
                                const float* z_vals, const float* u, int u_row_stride, int R, int S,
                                int N_imp, int inv_uniform, float* pts, float* z_out,
                                gpn_stream_t stream) {
+  if (R == 0) return GPN_OK;  // empty batch (pointers may be null)
   GPN_REQUIRE(ray_o && ray_d && weights && z_vals && u && pts && z_out,
               "gpn_sample_fine: null pointer");
   GPN_REQUIRE(R >= 0 && S >= 3 && N_imp >= 1 && S + N_imp <= 256,
@@ -212,6 +216,7 @@ extern "C" int gpn_sample_fine(const float* ray_o, const float* ray_d, const flo
 extern "C" int gpn_sample_pdf(const float* bins, const float* weights, const float* u,
                               int u_row_stride, int R, int M, int N_samples, float* samples,
                               gpn_stream_t stream) {
+  if (R == 0) return GPN_OK;  // empty batch (pointers may be null)
   GPN_REQUIRE(bins && weights && u && samples, "gpn_sample_pdf: null pointer");
   GPN_REQUIRE(R >= 0 && M >= 1 && M <= 4096 && N_samples >= 1, "gpn_sample_pdf: bad shape");
   GPN_REQUIRE(u_row_stride == 0 || u_row_stride >= N_samples, "gpn_sample_pdf: bad u_row_stride");
@@ -226,6 +231,7 @@ extern "C" int gpn_sample_pdf(const float* bins, const float* weights, const flo
 extern "C" int gpn_raw2outputs(const float* raw, const float* z_vals, const float* vis_mask, int R,
                                int S, int white_bkgd, float* rgb, float* depth, float* weights,
                                float* alpha, float* ray_mask, gpn_stream_t stream) {
+  if (R == 0) return GPN_OK;  // empty batch (pointers may be null)
   GPN_REQUIRE(raw && z_vals && vis_mask && rgb && depth && weights && alpha && ray_mask,
               "gpn_raw2outputs: null pointer");
   GPN_REQUIRE(R >= 0 && S >= 1, "gpn_raw2outputs: bad shape");

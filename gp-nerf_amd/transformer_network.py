@@ -185,9 +185,8 @@ class GNT(nn.Module):
         mask = _lib.dev_f32(_lib.as_f32c(mask), "mask").reshape(R, S, V)
         pts = _lib.dev_f32(_lib.as_f32c(pts), "pts", (R, S, 3))
         ray_d = _lib.dev_f32(_lib.as_f32c(ray_d), "ray_d", (R, 3))
-        if S % 16 or S < 16 or S > _lib.MAX_SAMPLES:
-            raise ValueError("samples per ray must be a multiple of 16 in [16,%d] (got %d)"
-                             % (_lib.MAX_SAMPLES, S))
+        if S < 1 or S > _lib.MAX_SAMPLES:
+            raise ValueError("samples per ray must be in [1,%d] (got %d)" % (_lib.MAX_SAMPLES, S))
         W = self._weights()
         ws, need = self._workspace(R, S, V, dev)
         out = torch.empty((R, 3 + S), device=dev)

@@ -166,7 +166,7 @@ int gpn_qpos(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* q_in
 /* Attention part of the ray Transformer, transformer_network.py:149-178 and :203-208.
  * x_in [R,S,C] -> x_out [R,S,C]; abar [R,4,S] = mean over queries of A (may be NULL);
  * weights [R,S] = head-mean of attention row 0 (transformer_network.py:216; may be NULL).
- * S must be a multiple of 16, 16 <= S <= GPN_MAX_SAMPLES. */
+ * 1 <= S <= GPN_MAX_SAMPLES (any S; multiples of 16 waste no lanes). */
 int gpn_ray_attn(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,
                  float* abar, float* weights, gpn_stream_t stream);
 

@@ -102,30 +102,64 @@ def test_projector_taps_and_helpers(dev):
 
 
 def test_projector_ragged_and_empty(dev):
+    """Results must not depend on the batch: every ragged sub-batch equals the same rows of the
+    full-batch oracle bit for bit.  (torch's own CPU bmm switches kernels for < ~32 points and then
+    rounds differently from itself -- measured: 35 of 700 rgb_feat values and 1 mask bit differ between
+    oracle(pts[:3,:5]) and oracle(pts)[:3,:5] -- so tiny batches are checked against the full run.)"""
     from gp_nerf_amd.projection import Projector
     c = cases.g1_projector()
     cd = to(dev, c)
     P = Projector(dev)
-    for R in (0, 1, 3, 37):
-        pts = cd["pts"][:R, :5].contiguous()
+    full = oracle.projector.compute(c["pts"], c["camera"], c["src_rgbs"], c["src_cameras"],
+                                    c["featmaps"], c["deep_semantics"])
+    for R, S in ((0, 5), (1, 5), (3, 5), (37, 5), (1, 16), (64, 1), (33, 7)):
+        pts = cd["pts"][:R, :S].contiguous()
         got = P.compute(pts, cd["camera"], cd["src_rgbs"], cd["src_cameras"], cd["featmaps"],
                         cd["deep_semantics"])
-        want = oracle.projector.compute(c["pts"][:R, :5], c["camera"], c["src_rgbs"],
-                                        c["src_cameras"], c["featmaps"], c["deep_semantics"])
-        for gt, wt, nm in zip(got, want, ("rgb_feat", "deep", "ray_diff", "mask")):
+        for gt, wt, nm in zip(got, full, ("rgb_feat", "deep", "ray_diff", "mask")):
+            wt = wt[:R, :S]
             assert tuple(gt.shape) == tuple(wt.shape), nm
-            if R and nm != "ray_diff":
-                assert torch.equal(gt.cpu(), wt), "%s R=%d" % (nm, R)
-    with pytest.raises(RuntimeError):
+            if nm == "ray_diff":
+                assert R == 0 or rel(gt, wt) < 1e-5
+            else:
+                assert torch.equal(gt.cpu(), wt), "%s R=%d S=%d" % (nm, R, S)
+    with pytest.raises(RuntimeError):  # CPU tensors are refused: there is no CPU fallback
         P.compute(c["pts"], c["camera"], c["src_rgbs"], c["src_cameras"], c["featmaps"], None)
 
 
 # ------------------------------------------------------------------------------ samplers
+def _pdf_reference(bins, weights, u):
+    """oracle.sampling.sample_pdf plus the per-sample conditioning data the comparison needs."""
+    w = weights + 1e-5
+    pdf = w / torch.sum(w, dim=-1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, dim=-1)], dim=-1)
+    above = (u[:, :, None] >= cdf[:, None, :-1]).sum(-1)
+    below = torch.clamp(above - 1, min=0)
+    denom = torch.gather(cdf, 1, above) - torch.gather(cdf, 1, below)
+    width = (torch.gather(bins, 1, above) - torch.gather(bins, 1, below)).abs()
+    return denom, width
+
+
+def _check_pdf_samples(got, want, denom, width, scale):
+    """fp32 noise in the cdf (torch.sum's reduction order is not reproducible) is amplified by
+    1/pdf(bin): |dz| <= 4e-7/denom * bin width.  Samples whose bin sits on the reference's own
+    `denom < 1e-5 -> 1` knife edge (within a few ulps of the cdf) are chaotic in the reference too
+    (they jump by a whole bin) and are only required to stay inside their bin."""
+    err = (got - want).abs()
+    edge = (denom - 1e-5).abs() < 5e-7
+    bound = 2e-6 * scale + 4e-7 / torch.clamp(denom, min=1e-5) * width
+    ok = (err <= bound) | (edge & (err <= width * 1.001 + 1e-6))
+    assert bool(ok.all()), "max excess %g (knife-edge samples: %d)" % (
+        float((err - bound)[~ok].max()), int(edge.sum()))
+    return int(edge.sum())
+
+
 def test_samplers(dev, golden):
     from gp_nerf_amd import render_ray as rr
     g = golden("g3_samplers")
     c = cases.g3_samplers()
     cd = to(dev, c)
+    u16 = torch.linspace(0.0, 1.0, 16)[None].repeat(c["weights"].shape[0], 1)
     for inv, tag in ((False, "lin"), (True, "inv")):
         pts, z = rr.sample_along_camera_ray(cd["ray_o"], cd["ray_d"], cd["depth_range"], 48,
                                             inv_uniform=inv, det=True)
@@ -134,8 +168,27 @@ def test_samplers(dev, golden):
         w0 = cd["weights"].clone()
         fpts, fz = rr.sample_fine_pts(inv, 16, True, 48, cd, cd["weights"], z)
         assert torch.equal(w0, cd["weights"]), "caller weights were mutated"
-        assert rel(fz, g["fz_" + tag]) < 1e-5 and rel(fpts, g["fpts_" + tag]) < 1e-5
-        assert bool((fz[:, 1:] >= fz[:, :-1]).all()), "fine depths must be sorted"
+        fzc = fz.cpu()
+        assert bool((fzc[:, 1:] >= fzc[:, :-1]).all()), "fine depths must be sorted"
+        assert rel(fpts, fzc[..., None] * c["ray_d"][:, None] + c["ray_o"][:, None]) < 1e-6
+        # the 16 new depths, per sample, against the reference's sample_pdf
+        zc = z.cpu()
+        if inv:
+            bins = torch.flip(0.5 * (1.0 / zc[:, 1:] + 1.0 / zc[:, :-1]), dims=[1])
+            wsel = torch.flip(c["weights"][:, 1:-1], dims=[1])
+        else:
+            bins = 0.5 * (zc[:, 1:] + zc[:, :-1])
+            wsel = c["weights"][:, 1:-1]
+        want = oracle.sampling.sample_pdf(bins, wsel, 16, det=True)
+        got = rr.sample_pdf(bins.to(dev), wsel.to(dev).contiguous(), 16, det=True).cpu()
+        denom, width = _pdf_reference(bins, wsel, u16)
+        _check_pdf_samples(got, want, denom, width, float(bins.abs().max()))
+        # merged + sorted list vs the golden run: well-conditioned rays to 1e-5
+        good = (denom.min(dim=-1)[0] > 2e-3).numpy()
+        assert good.sum() >= 3
+        assert rel(fzc[good], g["fz_" + tag][good]) < 1e-5
+        merged = torch.sort(torch.cat([zc, (1.0 / got) if inv else got], -1), -1)[0]
+        assert rel(fzc, merged) < 1e-6
     # stochastic paths: same formulas with injected randoms
     torch.manual_seed(3)
     pts, z = rr.sample_along_camera_ray(cd["ray_o"], cd["ray_d"], cd["depth_range"], 48,
@@ -147,9 +200,12 @@ def test_samplers(dev, golden):
     hi = torch.cat([mids, zd[:, -1:]], -1)
     zc = z.cpu()
     assert bool(((zc >= torch.minimum(lo, hi) - 1e-6) & (zc <= torch.maximum(lo, hi) + 1e-6)).all())
-    # sample_pdf entry point
-    bins = torch.sort(torch.rand(7, 12), dim=-1)[0]
-    wts = torch.rand(7, 11)
+    fpts, fz = rr.sample_fine_pts(True, 16, False, 48, cd, cd["weights"], zd.to(dev))
+    assert bool((fz[:, 1:] >= fz[:, :-1]).all()) and fz.shape == (zd.shape[0], 64)
+    # sample_pdf entry point on explicit bins
+    g0 = torch.Generator().manual_seed(5)
+    bins = torch.sort(torch.rand(7, 12, generator=g0), dim=-1)[0]
+    wts = torch.rand(7, 11, generator=g0) + 0.05
     got = rr.sample_pdf(bins.to(dev), wts.to(dev), 9, det=True)
     assert rel(got, oracle.sampling.sample_pdf(bins, wts, 9, det=True)) < 1e-5
     # raw2outputs
@@ -160,6 +216,10 @@ def test_samplers(dev, golden):
         for k in ("rgb", "depth", "weights", "alpha"):
             assert rel(r[k], o[k]) < 1e-5, k
         assert torch.equal(r["mask"].cpu(), o["mask"])
+    # empty batch
+    e = torch.empty((0, 3), device=dev)
+    p0, z0 = rr.sample_along_camera_ray(e, e, cd["depth_range"], 48, inv_uniform=True, det=True)
+    assert p0.shape == (0, 48, 3) and z0.shape == (0, 48)
 
 
 # ------------------------------------------------------------------------------ GNT stage by stage
@@ -172,7 +232,7 @@ def _stage_inputs(S, R=8):
     return c, rec, out
 
 
-@pytest.mark.parametrize("S", [48, 64])
+@pytest.mark.parametrize("S", [48, 64, 24, 100])
 def test_gnt_stages(dev, net, S):
     from gp_nerf_amd import _lib
     L = _lib.lib()
@@ -186,14 +246,15 @@ def test_gnt_stages(dev, net, S):
     errs = {}
     # posenc
     emb = e(N, 128)
-    _lib.check(L.gpn_posenc(_lib.ptr(f(c["pts"])), _lib.ptr(f(c["ray_d"])), R, S, _lib.ptr(emb), st), "posenc")
+    pts_d, rayd_d, rgbf_d = f(c["pts"]), f(c["ray_d"]), f(c["rgb_feat"])  # keep alive: kernels are async
+    _lib.check(L.gpn_posenc(_lib.ptr(pts_d), _lib.ptr(rayd_d), R, S, _lib.ptr(emb), st), "posenc")
     want = torch.cat([rec["pos_enc"].reshape(N, 63),
                       rec["view_enc"][:, None].expand(R, S, 63).reshape(N, 63),
                       torch.zeros(N, 2)], -1)
     errs["posenc"] = rel(emb, want)
     # rgbfeat
     feat, q0 = e(N, V, 64), e(N, 64)
-    _lib.check(L.gpn_rgbfeat(C.byref(W.rgbfeat0), C.byref(W.rgbfeat2), _lib.ptr(f(c["rgb_feat"])), N, V,
+    _lib.check(L.gpn_rgbfeat(C.byref(W.rgbfeat0), C.byref(W.rgbfeat2), _lib.ptr(rgbf_d), N, V,
                              35, _lib.ptr(feat), _lib.ptr(q0), st), "rgbfeat")
     errs["feat"] = rel(feat, rec["feat"].reshape(N, V, 64))
     errs["q0"] = rel(q0, rec["q0"].reshape(N, 64))
@@ -210,20 +271,22 @@ def test_gnt_stages(dev, net, S):
         errs["attn2d%d" % l] = rel(attn, rec["attn2d"][l].reshape(N, V, 64))
         vl = W.view[l]
         q2 = e(N, 64)
+        ff_in = f(rec["q_view_attn"][l].reshape(N, 64))
         _lib.check(L.gpn_ff(vl.ff_norm_w, vl.ff_norm_b, C.byref(vl.ff1), C.byref(vl.ff2),
-                            _lib.ptr(f(rec["q_view_attn"][l].reshape(N, 64))), N, _lib.ptr(q2), st), "ff")
+                            _lib.ptr(ff_in), N, _lib.ptr(q2), st), "ff")
         errs["view_ff%d" % l] = rel(q2, rec["q_view"][l].reshape(N, 64))
         if l % 2 == 0:
             q3 = e(N, 64)
-            _lib.check(L.gpn_qpos(C.byref(W.qfc0[l]), C.byref(W.qfc2[l]),
-                                  _lib.ptr(f(rec["q_view"][l].reshape(N, 64))), _lib.ptr(emb_ref), N,
-                                  _lib.ptr(q3), st), "qpos")
+            qp_in = f(rec["q_view"][l].reshape(N, 64))
+            _lib.check(L.gpn_qpos(C.byref(W.qfc0[l]), C.byref(W.qfc2[l]), _lib.ptr(qp_in),
+                                  _lib.ptr(emb_ref), N, _lib.ptr(q3), st), "qpos")
             errs["qpos%d" % l] = rel(q3, rec["q_pos"][l // 2].reshape(N, 64))
             x_in = rec["q_pos"][l // 2]
         else:
             x_in = rec["q_view"][l]
         xo, ab, wt = e(R, S, 64), e(R, 4, S), e(R, S)
-        _lib.check(L.gpn_ray_attn(C.byref(W.ray[l]), _lib.ptr(f(x_in)), R, S, _lib.ptr(xo), _lib.ptr(ab),
+        x_in_d = f(x_in)
+        _lib.check(L.gpn_ray_attn(C.byref(W.ray[l]), _lib.ptr(x_in_d), R, S, _lib.ptr(xo), _lib.ptr(ab),
                                   _lib.ptr(wt), st), "ray")
         errs["ray_attn%d" % l] = rel(xo, rec["q_ray_attn"][l])
         errs["abar%d" % l] = rel(ab, rec["A"][l].mean(dim=2))

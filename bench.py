@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""Benchmark of the GP-NeRF ray-rendering hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1], named in config.workload): Replica-shaped synthetic scene,
+640x480 image, 10 source views (RGB [10,480,640,3], features [10,32,120,160], deep semantics
+[10,512,240,320]), random-init GNT (netwidth 64, depth 8).  One step = one `render_rays` call on a
+chunk of 4096 rays with the reference's eval settings (48 coarse + 16 importance samples -> a 48-sample
+pass and a 64-sample pass, inv_uniform, det, single_net, ret_alpha, feats_out_3d materialised), all
+inputs resident in HBM, outputs left on the device.  With N>1 every rank renders its own 4096-ray
+chunk from its row shard of the image (weak scaling) and the rgb/depth/feats_out tiles of both
+levels are all-gathered over RCCL inside the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_view_attn, fp32 MFMA):
+algorithmic flops per launch / mean launch duration measured with HIP events inside the timed
+steps.  `cpu_baseline` is the CPU oracle (a port of the reference path) on a bounded ray sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CHUNK = 4096
+N_SAMPLES, N_IMPORTANCE, VIEWS = 48, 16, 10
+FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
+
+
+def view_attn_flops_per_point(V):
+    """Algorithmic flops (MAC = 2) of the attention half of one view-transformer layer per ray
+    sample: per view k_fc + v_fc (2 x 8192), pos_fc (4->8->64: 1088), attn_fc (64->8->64: 2048);
+    per sample q_fc + out_fc (2 x 8192).  (SURVEY.md 8(d) minus the deep-semantic MAC and the FF,
+    which run in other kernels here.)"""
+    return V * (2 * 8192 + 1088 + 2048) + 2 * 8192
+
+
+def build(dev, seed=1234):
+    from gp_nerf_amd import synth
+    from gp_nerf_amd.projection import Projector
+    from gp_nerf_amd.transformer_network import GNT
+    import numpy as np
+
+    H, W = 480, 640
+    K = synth.REPLICA_K
+    g = torch.Generator(device=dev).manual_seed(seed)
+    scene = types.SimpleNamespace()
+    scene.H, scene.W = H, W
+    scene.camera = torch.from_numpy(synth.make_camera(H, W, K, np.eye(4)))[None].to(dev)
+    scene.src_cameras = torch.from_numpy(synth.source_rig(VIEWS, H, W, K))[None].to(dev)
+    scene.depth_range = torch.tensor([[0.1, 10.0]], device=dev)
+    scene.src_rgbs = torch.rand((1, VIEWS, H, W, 3), device=dev, generator=g)
+    scene.featmaps = torch.randn((VIEWS, 32, H // 4, W // 4), device=dev, generator=g)
+    scene.deep = torch.randn((VIEWS, 512, H // 2, W // 2), device=dev, generator=g)
+    scene.rays_o, scene.rays_d = synth.rays_single_image(H, W, K, np.eye(4), 1)
+    args = types.SimpleNamespace(netwidth=64, trans_depth=8, save_feature=False,
+                                 semantic_model="fpn", num_classes=20)
+    net = GNT(args, 32, 63, 63, ret_alpha=True)
+    net.load_state_dict(synth.gnt_state_dict())
+    net = net.to(dev).eval()
+    return scene, net, Projector(dev)
+
+
+def ray_chunk(scene, rank, world, dev):
+    """4096 rays from the middle of this rank's row shard (rank 0 of 1: pixel (H/2)*W onwards)."""
+    from gp_nerf_amd.render_image import shard_rows
+    rows, parts = shard_rows(scene.H, world)
+    r0, r1 = parts[rank]
+    start = ((r0 + r1) // 2) * scene.W
+    start = min(start, scene.H * scene.W - CHUNK)
+    sl = slice(start, start + CHUNK)
+    return {"ray_o": scene.rays_o[sl].to(dev), "ray_d": scene.rays_d[sl].to(dev),
+            "depth_range": scene.depth_range, "camera": scene.camera,
+            "src_rgbs": scene.src_rgbs, "src_cameras": scene.src_cameras}
+
+
+def cpu_baseline(scene, rb, n_rays):
+    """The CPU oracle (port of the reference path) on the first `n_rays` rays of the same chunk."""
+    import oracle
+    from gp_nerf_amd import synth
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    sd = synth.gnt_state_dict()
+    rbc = {k: v.cpu() for k, v in rb.items()}
+    rbc["ray_o"], rbc["ray_d"] = rbc["ray_o"][:n_rays], rbc["ray_d"][:n_rays]
+    feat, deep = scene.featmaps.cpu(), scene.deep.cpu()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        out = oracle.render.render_rays(rbc, sd, feat, deep, N_samples=N_SAMPLES, inv_uniform=True,
+                                        N_importance=N_IMPORTANCE, det=True, ret_alpha=True)
+    dt = time.perf_counter() - t0
+    return out, {"value": n_rays / dt, "unit": "rays/s", "cores": threads, "kind": "port",
+                 "sample": "%d rays of the same chunk, full two-pass (48+16) render_rays, torch-CPU "
+                           "fp32 oracle, %.1f s" % (n_rays, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cpu-rays", type=int, default=1536, help="rays of the CPU baseline sample (0: skip)")
+    ap.add_argument("--breakdown", action="store_true", help="print a per-stage time table to stderr")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per "
+                     "GPU); WORLD_SIZE is 1" % a.gpus)
+        a.gpus = world
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from gp_nerf_amd import _lib
+    from gp_nerf_amd.render_ray import render_rays
+    _lib.lib()
+    scene, net, projector = build(dev)
+    model = types.SimpleNamespace(net_coarse=net, net_fine=None)
+    rb = ray_chunk(scene, rank, world, dev)
+    tile_w = 2 * (3 + 1 + 512)
+    gathered = torch.empty((world * CHUNK, tile_w), device=dev) if world > 1 else None
+
+    def step():
+        ret = render_rays(rb, model, scene.featmaps, scene.deep, projector, N_samples=N_SAMPLES,
+                          inv_uniform=True, N_importance=N_IMPORTANCE, det=True, ret_alpha=True,
+                          single_net=True)
+        if world > 1:  # rgb / depth / semantic tiles of both levels, one collective
+            c, f = ret["outputs_coarse"], ret["outputs_fine"]
+            tile = torch.cat([c["rgb"], c["depth"][:, None], c["feats_out"],
+                              f["rgb"], f["depth"][:, None], f["feats_out"]], dim=1)
+            dist.all_gather_into_tensor(gathered, tile)
+        return ret
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        ret = step()
+    fence()
+    t0 = time.perf_counter()
+    with _lib.stage_timing(stages=("view_attn",), max_records=32 * a.steps + 64) as tm:
+        for _ in range(a.steps):
+            ret = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel: k_view_attn, 8 launches on N=4096*48 points + 8 on N=4096*64 per step
+    launches = tm.launches["view_attn"]
+    mean_ms = tm.ms["view_attn"] / max(1, launches)
+    flops_per_launch = view_attn_flops_per_point(VIEWS) * CHUNK * (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) / 2.0
+    achieved = flops_per_launch / (mean_ms * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": "k_view_attn", "achieved": achieved,
+                "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                "launches": launches, "mean_launch_ms": mean_ms,
+                "flops_per_launch": flops_per_launch}
+
+    stages = None
+    if a.breakdown or rank == 0:
+        with _lib.stage_timing() as tb:  # one extra, untimed step with every stage instrumented
+            step()
+            torch.cuda.synchronize()
+        stages = {k: round(v, 4) for k, v in tb.ms.items() if tb.launches[k]}
+        if a.breakdown and rank == 0:
+            print("per-stage ms (one step):", json.dumps(stages), file=sys.stderr)
+
+    cpu = None
+    if rank == 0 and world == 1 and a.cpu_rays > 0:
+        want, cpu = cpu_baseline(scene, rb, a.cpu_rays)
+        worst = 0.0
+        for lvl in ("outputs_coarse", "outputs_fine"):
+            for k in ("rgb", "depth", "weights", "feats_out"):
+                x, y = ret[lvl][k][:a.cpu_rays].cpu(), want[lvl][k]
+                worst = max(worst, float((x - y).abs().max() / max(1.0, float(y.abs().max()))))
+        cpu["max_rel_err_gpu_vs_cpu"] = worst
+
+    if rank == 0:
+        rays = world * CHUNK * a.steps
+        line = {
+            "metric": "rays_per_sec", "value": rays / elapsed, "unit": "rays/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "replica_640x480_10views render_rays chunk=4096 rays/GPU, "
+                                   "coarse 48 + importance 16 (48- and 64-sample passes), fp32",
+                       "rays_per_step_per_gpu": CHUNK, "samples": [N_SAMPLES, N_SAMPLES + N_IMPORTANCE],
+                       "views": VIEWS, "parallelism": "ray-sharded x%d" % world},
+            "roofline": roofline, "cpu_baseline": cpu, "stage_ms_one_step": stages,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -101,7 +101,12 @@ _SIGS = {
     "gpn_gnt_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "gpn_gnt_forward": (C.c_int, [C.POINTER(GntWeights), _P, _P, _P, _P, _P, _P, C.c_int, C.c_int,
                                   C.c_int, C.POINTER(SemArgs), _P, _P, _P, _P, C.c_size_t, _P]),
+    "gpn_timing_begin": (C.c_int, [C.c_uint, C.c_int]),
+    "gpn_timing_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
 }
+
+STAGES = ("sample", "project", "project_deep", "posenc", "rgbfeat", "view_attn", "ff", "qpos",
+          "ray_attn", "sem", "heads")
 
 EXPORTS = tuple(_SIGS)
 _lib = None
@@ -160,3 +165,25 @@ def as_f32c(t):
     if t.dtype != torch.float32:
         t = t.float()
     return t if t.is_contiguous() else t.contiguous()
+
+
+class stage_timing:
+    """Context manager around gpn_timing_begin / gpn_timing_end: per-stage kernel time measured
+    with HIP events on the launch stream.  `.ms` / `.launches` map stage name -> totals."""
+
+    def __init__(self, stages=STAGES, max_records=8192):
+        self.mask = sum(1 << STAGES.index(s) for s in stages)
+        self.max_records = max_records
+        self.ms, self.launches = {}, {}
+
+    def __enter__(self):
+        check(lib().gpn_timing_begin(self.mask, self.max_records), "gpn_timing_begin")
+        return self
+
+    def __exit__(self, *exc):
+        ms = (C.c_double * len(STAGES))()
+        cnt = (C.c_longlong * len(STAGES))()
+        check(lib().gpn_timing_end(ms, cnt), "gpn_timing_end")
+        self.ms = {s: ms[i] for i, s in enumerate(STAGES)}
+        self.launches = {s: cnt[i] for i, s in enumerate(STAGES)}
+        return False

@@ -22,3 +22,17 @@ static inline int gpn_ceil_div(long long a, long long b) { return (int)((a + b -
 
 // Number of compute units of the current device (cached); grids of persistent kernels scale with it.
 int gpn_num_cus();
+
+// Optional per-stage event timing (see gpn_timing_begin in the header).  Construct right before a
+// kernel launch; the destructor records the closing event after it.
+class GpnStageTimer {
+ public:
+  GpnStageTimer(int stage, hipStream_t stream);
+  ~GpnStageTimer();
+  GpnStageTimer(const GpnStageTimer&) = delete;
+  GpnStageTimer& operator=(const GpnStageTimer&) = delete;
+
+ private:
+  int slot_;
+  hipStream_t stream_;
+};

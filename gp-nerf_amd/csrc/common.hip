@@ -3,6 +3,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -29,3 +30,62 @@ int gpn_num_cus() {
 
 extern "C" int gpn_abi_version(void) { return GPN_ABI_VERSION; }
 extern "C" const char* gpn_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------- per-stage event timing
+namespace {
+struct TimingRec {
+  hipEvent_t a, b;
+  int stage;
+};
+std::vector<TimingRec> g_pool;
+int g_used = 0;
+unsigned g_mask = 0;
+}  // namespace
+
+GpnStageTimer::GpnStageTimer(int stage, hipStream_t stream) : slot_(-1), stream_(stream) {
+  if (((g_mask >> stage) & 1u) && g_used < (int)g_pool.size()) {
+    slot_ = g_used++;
+    g_pool[slot_].stage = stage;
+    (void)hipEventRecord(g_pool[slot_].a, stream_);
+  }
+}
+GpnStageTimer::~GpnStageTimer() {
+  if (slot_ >= 0) (void)hipEventRecord(g_pool[slot_].b, stream_);
+}
+
+extern "C" int gpn_timing_begin(unsigned stage_mask, int max_records) {
+  GPN_REQUIRE(g_pool.empty(), "gpn_timing_begin: a timing session is already open");
+  GPN_REQUIRE(max_records > 0 && max_records <= (1 << 20), "gpn_timing_begin: bad max_records");
+  g_pool.resize(max_records);
+  for (auto& r : g_pool) {
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess)
+      return gpn_set_error(GPN_E_LAUNCH, "gpn_timing_begin: hipEventCreate failed");
+  }
+  g_used = 0;
+  g_mask = stage_mask;
+  return GPN_OK;
+}
+
+extern "C" int gpn_timing_end(double* ms_per_stage, long long* launches_per_stage) {
+  GPN_REQUIRE(ms_per_stage && launches_per_stage, "gpn_timing_end: null pointer");
+  g_mask = 0;
+  for (int i = 0; i < GPN_NSTAGES; ++i) ms_per_stage[i] = 0.0, launches_per_stage[i] = 0;
+  int rc = GPN_OK;
+  for (int i = 0; i < g_used; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(g_pool[i].b) != hipSuccess ||
+        hipEventElapsedTime(&ms, g_pool[i].a, g_pool[i].b) != hipSuccess) {
+      rc = gpn_set_error(GPN_E_LAUNCH, "gpn_timing_end: event query failed");
+      break;
+    }
+    ms_per_stage[g_pool[i].stage] += ms;
+    launches_per_stage[g_pool[i].stage] += 1;
+  }
+  for (auto& r : g_pool) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  g_pool.clear();
+  g_used = 0;
+  return rc;
+}

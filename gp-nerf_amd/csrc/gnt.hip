@@ -719,6 +719,7 @@ extern "C" int gpn_posenc(const float* pts, const float* ray_d, int R, int S, fl
   GPN_REQUIRE(R >= 0 && S >= 1, "gpn_posenc: bad shape");
   const long long N = (long long)R * S;
   if (N == 0) return GPN_OK;
+  GpnStageTimer timer_k_posenc_(GPN_ST_POSENC, (hipStream_t)stream);
   hipLaunchKernelGGL(k_posenc, dim3(gpn_ceil_div(N * GPN_EMB, 256)), dim3(256), 0,
                      (hipStream_t)stream, pts, ray_d, S, N, emb);
   GPN_LAUNCH_CHECK("k_posenc");
@@ -737,6 +738,7 @@ extern "C" int gpn_rgbfeat(const gpn_linear_t* fc0, const gpn_linear_t* fc2, con
   if (N == 0) return GPN_OK;
   const size_t lds = sizeof(float) * (64 * RF_LD0 + 64 * LDW + 128);
   const int grid = persistent_grid(((long long)N + 127) / 128);
+  GpnStageTimer timer_k_rgbfeat_(GPN_ST_RGBFEAT, (hipStream_t)stream);
   hipLaunchKernelGGL(k_rgbfeat, dim3(grid), dim3(512), lds, (hipStream_t)stream, *fc0, *fc2,
                      rgb_feat, (long long)N, V, in_ch, feat, q0);
   GPN_LAUNCH_CHECK("k_rgbfeat");
@@ -763,6 +765,7 @@ extern "C" int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const
   int rc = set_lds_limit(reinterpret_cast<const void*>(k_view_attn), lds);
   if (rc) return rc;
   const int grid = persistent_grid(((long long)N + 127) / 128);
+  GpnStageTimer timer_k_view_attn_(GPN_ST_VIEW_ATTN, (hipStream_t)stream);
   hipLaunchKernelGGL(k_view_attn, dim3(grid), dim3(512), lds, (hipStream_t)stream, *L, q_in, feat,
                      ray_diff, mask, (long long)N, V, q_out, logits, stats);
   GPN_LAUNCH_CHECK("k_view_attn");
@@ -783,6 +786,7 @@ extern "C" int gpn_ff(const float* norm_w, const float* norm_b, const gpn_linear
   int rc = set_lds_limit(reinterpret_cast<const void*>(k_ff), lds);
   if (rc) return rc;
   const int grid = persistent_grid(((long long)N + 127) / 128);
+  GpnStageTimer timer_k_ff_(GPN_ST_FF, (hipStream_t)stream);
   hipLaunchKernelGGL(k_ff, dim3(grid), dim3(512), lds, (hipStream_t)stream, norm_w, norm_b, *fc1,
                      *fc2, x_in, (long long)N, x_out);
   GPN_LAUNCH_CHECK("k_ff");
@@ -803,6 +807,7 @@ extern "C" int gpn_qpos(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const 
   int rc = set_lds_limit(reinterpret_cast<const void*>(k_qpos), lds);
   if (rc) return rc;
   const int grid = persistent_grid(((long long)N + 127) / 128);
+  GpnStageTimer timer_k_qpos_(GPN_ST_QPOS, (hipStream_t)stream);
   hipLaunchKernelGGL(k_qpos, dim3(grid), dim3(512), lds, (hipStream_t)stream, *fc0, *fc2, q_in, emb,
                      (long long)N, q_out);
   GPN_LAUNCH_CHECK("k_qpos");
@@ -817,6 +822,7 @@ static int launch_ray_attn(const gpn_ray_layer_t* L, const float* x_in, int R, i
   int rc = set_lds_limit(reinterpret_cast<const void*>(k_ray_attn<NT>), lds);
   if (rc) return rc;
   const int grid = persistent_grid(((long long)R + Cfg::RPW - 1) / Cfg::RPW);
+  GpnStageTimer timer_k_ray_attn_(GPN_ST_RAY_ATTN, (hipStream_t)stream);
   hipLaunchKernelGGL(k_ray_attn<NT>, dim3(grid), dim3(Cfg::THREADS), lds, stream, *L, x_in, R, S,
                      x_out, abar, weights);
   GPN_LAUNCH_CHECK("k_ray_attn");
@@ -868,6 +874,7 @@ extern "C" int gpn_sem_aggregate(const gpn_sem_args_t* a, gpn_stream_t stream) {
   }
   GPN_REQUIRE(aligned16(a->pre) && aligned16(a->sem3d), "gpn_sem_aggregate: outputs must be aligned");
   if (a->R == 0) return GPN_OK;
+  GpnStageTimer timer_k_sem_(GPN_ST_SEM, (hipStream_t)stream);
   hipLaunchKernelGGL(k_sem, dim3(a->R), dim3(256), 0, (hipStream_t)stream, *a);
   GPN_LAUNCH_CHECK("k_sem");
   return GPN_OK;
@@ -881,13 +888,17 @@ extern "C" int gpn_heads(const gpn_gnt_weights_t* W, const float* q, const float
   GPN_REQUIRE(W->norm_w && W->norm_b && W->rgb_fc.w, "gpn_heads: null weight");
   GPN_REQUIRE(R >= 0 && S >= 1, "gpn_heads: bad shape");
   if (R == 0) return GPN_OK;
-  hipLaunchKernelGGL(k_heads_rgb, dim3(gpn_ceil_div(R, 4)), dim3(256), 0, (hipStream_t)stream,
-                     W->norm_w, W->norm_b, W->rgb_fc, q, weights, z_vals, R, S, out, depth);
-  GPN_LAUNCH_CHECK("k_heads_rgb");
+  {
+    GpnStageTimer timer_k_heads_rgb_(GPN_ST_HEADS, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_heads_rgb, dim3(gpn_ceil_div(R, 4)), dim3(256), 0, (hipStream_t)stream,
+                       W->norm_w, W->norm_b, W->rgb_fc, q, weights, z_vals, R, S, out, depth);
+    GPN_LAUNCH_CHECK("k_heads_rgb");
+  }
   if (pre != nullptr) {
     GPN_REQUIRE(sem_feat, "gpn_heads: pre given without sem_feat");
     REQ_LIN(W->sem_adaptor, "gpn_heads.sem_adaptor");
     GPN_REQUIRE(aligned16(pre) && aligned16(sem_feat), "gpn_heads: sem tensors must be aligned");
+    GpnStageTimer timer_k_sem_adaptor_(GPN_ST_HEADS, (hipStream_t)stream);
     hipLaunchKernelGGL(k_sem_adaptor, dim3(gpn_ceil_div(R, 16)), dim3(256), 0, (hipStream_t)stream,
                        W->sem_adaptor, pre, R, sem_feat);
     GPN_LAUNCH_CHECK("k_sem_adaptor");

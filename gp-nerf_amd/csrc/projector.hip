@@ -206,12 +206,14 @@ extern "C" int gpn_project_gather(const gpn_project_args_t* a, gpn_stream_t stre
   {
     const long long blocks = (n_pairs + PAIRS - 1) / PAIRS;
     const int grid = (int)(blocks < (long long)cus * 16 ? blocks : (long long)cus * 16);
+    GpnStageTimer timer_k_project_feat_(GPN_ST_PROJECT, (hipStream_t)stream);
     hipLaunchKernelGGL(k_project_feat, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, n_pairs);
     GPN_LAUNCH_CHECK("k_project_feat");
   }
   if (want_deep) {
     const long long blocks = (n_pairs + 3) / 4;
     const int grid = (int)(blocks < (long long)cus * 8 ? blocks : (long long)cus * 8);
+    GpnStageTimer timer_k_project_deep_(GPN_ST_PROJECT_DEEP, (hipStream_t)stream);
     hipLaunchKernelGGL(k_project_deep, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, n_pairs);
     GPN_LAUNCH_CHECK("k_project_deep");
   }

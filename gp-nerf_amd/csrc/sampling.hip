@@ -187,6 +187,7 @@ extern "C" int gpn_sample_along_ray(const float* ray_o, const float* ray_d, floa
               "gpn_sample_along_ray: need 0 < near < far (got %g, %g)", near_depth, far_depth);
   if (R == 0) return GPN_OK;
   const long long n = (long long)R * S;
+  GpnStageTimer timer_k_sample_along_ray_(GPN_ST_SAMPLE, (hipStream_t)stream);
   hipLaunchKernelGGL(k_sample_along_ray, dim3(gpn_ceil_div(n, 256)), dim3(256), 0,
                      (hipStream_t)stream, ray_o, ray_d, near_depth, far_depth, R, S, inv_uniform,
                      t_rand, pts, z_vals);
@@ -207,6 +208,7 @@ extern "C" int gpn_sample_fine(const float* ray_o, const float* ray_d, const flo
   if (R == 0) return GPN_OK;
   const int T = S + N_imp;
   const size_t lds = sizeof(float) * ((S - 1) + (S - 2) + (S - 1) + 2 * T);
+  GpnStageTimer timer_k_sample_fine_(GPN_ST_SAMPLE, (hipStream_t)stream);
   hipLaunchKernelGGL(k_sample_fine, dim3(R), dim3(64), lds, (hipStream_t)stream, ray_o, ray_d,
                      weights, z_vals, u, u_row_stride, R, S, N_imp, inv_uniform, pts, z_out);
   GPN_LAUNCH_CHECK("k_sample_fine");
@@ -222,6 +224,7 @@ extern "C" int gpn_sample_pdf(const float* bins, const float* weights, const flo
   GPN_REQUIRE(u_row_stride == 0 || u_row_stride >= N_samples, "gpn_sample_pdf: bad u_row_stride");
   if (R == 0) return GPN_OK;
   const size_t lds = sizeof(float) * (3 * M + 2);
+  GpnStageTimer timer_k_sample_pdf_(GPN_ST_SAMPLE, (hipStream_t)stream);
   hipLaunchKernelGGL(k_sample_pdf, dim3(R), dim3(64), lds, (hipStream_t)stream, bins, weights, u,
                      u_row_stride, M, N_samples, samples);
   GPN_LAUNCH_CHECK("k_sample_pdf");
@@ -236,6 +239,7 @@ extern "C" int gpn_raw2outputs(const float* raw, const float* z_vals, const floa
               "gpn_raw2outputs: null pointer");
   GPN_REQUIRE(R >= 0 && S >= 1, "gpn_raw2outputs: bad shape");
   if (R == 0) return GPN_OK;
+  GpnStageTimer timer_k_raw2outputs_(GPN_ST_SAMPLE, (hipStream_t)stream);
   hipLaunchKernelGGL(k_raw2outputs, dim3(gpn_ceil_div(R, 128)), dim3(128), 0, (hipStream_t)stream,
                      raw, z_vals, vis_mask, R, S, white_bkgd, rgb, depth, weights, alpha, ray_mask);
   GPN_LAUNCH_CHECK("k_raw2outputs");

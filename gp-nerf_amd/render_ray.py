@@ -17,9 +17,24 @@ def _f(t, name):
     return _lib.dev_f32(_lib.as_f32c(t), name)
 
 
+_range_cache = {}
+
+
+def _depth_range(depth_range):
+    """(near, far) as host floats; the device->host read happens once per tensor, not per chunk."""
+    key = (depth_range.data_ptr(), depth_range._version, str(depth_range.device))
+    hit = _range_cache.get(key)
+    if hit is None:
+        if len(_range_cache) > 64:
+            _range_cache.clear()
+        hit = (float(depth_range[0, 0]), float(depth_range[0, 1]), depth_range)
+        _range_cache[key] = hit
+    return hit[0], hit[1]
+
+
 def sample_along_camera_ray(ray_o, ray_d, depth_range, N_samples, inv_uniform=False, det=False):
     """reference render_ray.py:58-102 -> pts [R,S,3], z_vals [R,S]."""
-    near, far = float(depth_range[0, 0]), float(depth_range[0, 1])
+    near, far = _depth_range(depth_range)
     assert near > 0 and far > 0 and far > near
     ray_o, ray_d = _f(ray_o, "ray_o"), _f(ray_d, "ray_d")
     R = ray_d.shape[0]

@@ -208,6 +208,21 @@ int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat, const flo
                     int R, int S, int V, gpn_sem_args_t* sem, float* out, float* depth,
                     float* sem_feat, void* workspace, size_t workspace_bytes, gpn_stream_t stream);
 
+/* ------------------------------------------------------------------ measurement hooks
+ * No counterpart in the reference: bench.py uses these to time individual kernels with HIP events on
+ * the stream they are launched on, inside the timed region.  gpn_timing_begin creates `max_records`
+ * event pairs (outside any launch path); while enabled, every launch of a stage selected in
+ * `stage_mask` (bit i = stage i) is bracketed by an event pair; gpn_timing_end waits for the
+ * events, returns per-stage summed milliseconds and launch counts (arrays of GPN_NSTAGES) and
+ * releases the pool.  Not thread-safe; one session at a time. */
+enum {
+  GPN_ST_SAMPLE = 0, GPN_ST_PROJECT, GPN_ST_PROJECT_DEEP, GPN_ST_POSENC, GPN_ST_RGBFEAT,
+  GPN_ST_VIEW_ATTN, GPN_ST_FF, GPN_ST_QPOS, GPN_ST_RAY_ATTN, GPN_ST_SEM, GPN_ST_HEADS,
+  GPN_NSTAGES
+};
+int gpn_timing_begin(unsigned stage_mask, int max_records);
+int gpn_timing_end(double* ms_per_stage, long long* launches_per_stage);
+
 #ifdef __cplusplus
 }
 #endif

@@ -203,6 +203,10 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
       lrun[M] = f4_zero();
       acc[M] = f4_zero();
     }
+    // A masked view contributes exp(-1e9 - max) == 0 exactly as soon as the point has one visible
+    // view, so a (tile, view) whose 16 points are all masked-but-visible-elsewhere is skipped whole.
+    bool any_vis = false;
+    for (int v = 0; v < V; ++v) any_vis |= mask[(size_t)nc * V + v] != 0.0f;
     const float* frow = feat + (size_t)nc * V * C64 + 4 * g;
     f4 fcur[4];
 #pragma unroll
@@ -213,8 +217,13 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
       const int vn = v + 1 < V ? v + 1 : v;
 #pragma unroll
       for (int T = 0; T < 4; ++T) fnext[T] = ld4(frow + (size_t)vn * C64 + 16 * T);
-      const float rd = ray_diff[((size_t)nc * V + v) * 4 + g];
       const float mk = mask[(size_t)nc * V + v];
+      if (__all((mk == 0.0f) && any_vis)) {  // wave-uniform
+#pragma unroll
+        for (int T = 0; T < 4; ++T) fcur[T] = fnext[T];
+        continue;
+      }
+      const float rd = ray_diff[((size_t)nc * V + v) * 4 + g];
 
       f4 k[4], val[4];
 #pragma unroll
@@ -243,7 +252,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
 #pragma unroll
         for (int M = 0; M < 4; ++M) a[M] = f4_splat(-1e9f);  // masked_fill (:83)
       }
-      if (logits != nullptr && valid) {
+      if (logits != nullptr && valid && mk != 0.0f) {  // masked pairs are never read back
         float* lo = logits + ((size_t)n * V + v) * C64 + 4 * g;
 #pragma unroll
         for (int M = 0; M < 4; ++M) st4(lo + 16 * M, a[M]);
@@ -566,9 +575,11 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
 
 // ------------------------------------------------------------------------------------ semantic aggregation
 // One workgroup (256 threads) per ray; thread (half, c4) owns deep channels c4..c4+3 of the samples
-// s = half (mod 2).  Per (sample, view): attention weights of every layer are rebuilt from the stored
-// logits + softmax stats, summed into W3d / W2d (per 8-channel group), and applied to the bilinearly
-// sampled (or dense) 512-ch deep-semantic row.  Views whose weight is exactly 0 are skipped.
+// s = half (mod 2).  Per sample the softmax stats and abar of every layer are loaded once; per
+// visible (sample, view) the attention weights of every layer are rebuilt from the stored logits,
+// summed into W3d / W2d (per 8-channel group) and applied to the bilinearly sampled (or dense)
+// 512-ch deep-semantic row.  Masked views have weight exactly 0 and are skipped; a sample with no
+// visible view has the uniform weight 1/V in every layer (softmax of equal -1e9 logits).
 __global__ void __launch_bounds__(256)
 k_sem(gpn_sem_args_t a) {
   __shared__ float sP[GPN_MAX_VIEWS * 12];
@@ -584,37 +595,64 @@ k_sem(gpn_sem_args_t a) {
   const int c4 = lt * 4, grp = lt >> 1, head = grp >> 4;
   f4 acc2 = f4_zero();
   const size_t rs = (size_t)a.deep_w * GPN_SEM;
+  const float inv_v = 1.0f / (float)V;
   for (int s = half; s < S; s += 2) {
     const size_t n = (size_t)r * S + s;
-    bool any_vis = false;
-    for (int v = 0; v < V; ++v) any_vis |= a.mask[n * V + v] != 0.0f;
+    unsigned vis = 0;
+    for (int v = 0; v < V; ++v) vis |= (a.mask[n * V + v] != 0.0f ? 1u : 0u) << v;
+    float mx[GPN_MAX_DEPTH], rl[GPN_MAX_DEPTH], ab[GPN_MAX_DEPTH];
+    float w3u = 0.f, w2u = 0.f;  // uniform weights of an all-masked sample
+#pragma unroll
+    for (int l = 0; l < GPN_MAX_DEPTH; ++l) {
+      mx[l] = rl[l] = ab[l] = 0.f;
+      if (l < a.depth) {
+        ab[l] = a.abar[l][((size_t)r * 4 + head) * S + s];
+        if (vis != 0) {
+          mx[l] = a.stats[l][n * 128 + grp];
+          rl[l] = a.stats[l][n * 128 + 64 + grp];
+        }
+        w3u += inv_v;
+        w2u += ab[l] * inv_v;
+      }
+    }
     f4 acc3 = f4_zero();
     float px = 0.f, py = 0.f, pz = 0.f;
     if (a.deep_map != nullptr) px = a.xyz[n * 3 + 0], py = a.xyz[n * 3 + 1], pz = a.xyz[n * 3 + 2];
     for (int v = 0; v < V; ++v) {
-      if (any_vis && a.mask[n * V + v] == 0.0f) continue;  // softmax weight is exactly 0
-      float w3 = 0.f, w2 = 0.f;
-      for (int l = 0; l < a.depth; ++l) {
-        const float lg = a.logits[l][(n * V + v) * C64 + grp];
-        const float m = a.stats[l][n * 128 + grp];
-        const float rl = a.stats[l][n * 128 + 64 + grp];
-        const float at = __expf(lg - m) * rl;
-        w3 += at;
-        w2 += a.abar[l][((size_t)r * 4 + head) * S + s] * at;
-      }
-      f4 d;
+      if (vis != 0 && !((vis >> v) & 1u)) continue;  // softmax weight is exactly 0
+      // issue the deep-semantic loads first, the logits next; combine afterwards
+      f4 vnw = f4_zero(), vne = f4_zero(), vsw = f4_zero(), vse = f4_zero();
+      GpnTaps t;
       if (a.deep_dense != nullptr) {
-        d = ld4(a.deep_dense + (n * V + v) * GPN_SEM + c4);
+        vnw = ld4(a.deep_dense + (n * V + v) * GPN_SEM + c4);
       } else {
         const GpnPix pp = gpn_project(sP + v * 12, px, py, pz);
-        const GpnTaps t = gpn_taps(pp.px, pp.py, a.img_h, a.img_w, a.deep_h, a.deep_w);
+        t = gpn_taps(pp.px, pp.py, a.img_h, a.img_w, a.deep_h, a.deep_w);
         const float* dm = a.deep_map + (size_t)v * a.deep_h * rs + c4;
         const size_t o00 = (size_t)t.y0 * rs + (size_t)t.x0 * GPN_SEM;
-        f4 vnw = f4_zero(), vne = f4_zero(), vsw = f4_zero(), vse = f4_zero();
         if (t.vy0 && t.vx0) vnw = ld4(dm + o00);
         if (t.vy0 && t.vx1) vne = ld4(dm + o00 + GPN_SEM);
         if (t.vy1 && t.vx0) vsw = ld4(dm + o00 + rs);
         if (t.vy1 && t.vx1) vse = ld4(dm + o00 + rs + GPN_SEM);
+      }
+      float w3 = w3u, w2 = w2u;
+      if (vis != 0) {
+        float lg[GPN_MAX_DEPTH];
+#pragma unroll
+        for (int l = 0; l < GPN_MAX_DEPTH; ++l)
+          lg[l] = l < a.depth ? a.logits[l][(n * V + v) * C64 + grp] : 0.f;
+        w3 = 0.f, w2 = 0.f;
+#pragma unroll
+        for (int l = 0; l < GPN_MAX_DEPTH; ++l) {
+          if (l < a.depth) {
+            const float at = __expf(lg[l] - mx[l]) * rl[l];
+            w3 += at;
+            w2 += ab[l] * at;
+          }
+        }
+      }
+      f4 d = vnw;
+      if (a.deep_dense == nullptr) {
         d.x = gpn_bilerp(vnw.x, vne.x, vsw.x, vse.x, t);
         d.y = gpn_bilerp(vnw.y, vne.y, vsw.y, vse.y, t);
         d.z = gpn_bilerp(vnw.z, vne.z, vsw.z, vse.z, t);

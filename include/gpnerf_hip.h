@@ -149,8 +149,10 @@ int gpn_rgbfeat(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* r
 
 /* Attention part of Transformer2D (attn_norm, Attention2D, residual), transformer_network.py:74-88
  * and :107-112.  q_in [N,C], feat [N,V,C], ray_diff [N,V,4], mask [N,V] -> q_out [N,C];
- * logits [N,V,C] = masked pre-softmax attention, stats [N,2,C] = (max_v, 1/sum_v exp) so that the
- * per-channel view softmax of line :84 is exp(logit-max)*rsum. logits/stats may be NULL. */
+ * logits [N,V,C] = pre-softmax attention of the VISIBLE (point, view) pairs (mask != 0; entries of
+ * masked pairs are left unwritten: their softmax weight is exactly 0, or exactly 1/V when the
+ * point has no visible view at all); stats [N,2,C] = (max_v, 1/sum_v exp) so that the per-channel
+ * view softmax of line :84 is exp(logit-max)*rsum. logits/stats may be NULL. */
 int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const float* feat,
                   const float* ray_diff, const float* mask, int N, int V, float* q_out,
                   float* logits, float* stats, gpn_stream_t stream);

@@ -267,7 +267,11 @@ def test_gnt_stages(dev, net, S):
         _lib.check(L.gpn_view_attn(C.byref(W.view[l]), _lib.ptr(q_in), _lib.ptr(feat_ref), _lib.ptr(rd),
                                    _lib.ptr(mk), N, V, _lib.ptr(qo), _lib.ptr(lg), _lib.ptr(stt), st), "view")
         errs["view_attn%d" % l] = rel(qo, rec["q_view_attn"][l].reshape(N, 64))
-        attn = torch.exp(lg - stt[:, 0][:, None]) * stt[:, 1][:, None]
+        # logits of masked pairs are never written: weight 0, or 1/V for an all-masked point
+        vis = mk.reshape(N, V, 1) != 0
+        attn = torch.where(vis, torch.exp(lg - stt[:, 0][:, None]) * stt[:, 1][:, None],
+                           torch.zeros_like(lg))
+        attn = torch.where(vis.any(dim=1, keepdim=True), attn, torch.full_like(lg, 1.0 / V))
         errs["attn2d%d" % l] = rel(attn, rec["attn2d"][l].reshape(N, V, 64))
         vl = W.view[l]
         q2 = e(N, 64)

@@ -90,8 +90,10 @@ _SIGS = {
     "gpn_posenc": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "gpn_rgbfeat": (C.c_int, [C.POINTER(Linear), C.POINTER(Linear), _P, C.c_int, C.c_int, C.c_int,
                               _P, _P, _P]),
-    "gpn_view_attn": (C.c_int, [C.POINTER(ViewLayer), _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P,
-                                _P]),
+    "gpn_view_attn": (C.c_int, [C.POINTER(ViewLayer), _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P,
+                                _P, _P]),
+    "gpn_vis_order_scratch_bytes": (C.c_size_t, []),
+    "gpn_vis_order": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P]),
     "gpn_ff": (C.c_int, [_P, _P, C.POINTER(Linear), C.POINTER(Linear), _P, C.c_int, _P, _P]),
     "gpn_qpos": (C.c_int, [C.POINTER(Linear), C.POINTER(Linear), _P, _P, C.c_int, _P, _P]),
     "gpn_ray_attn": (C.c_int, [C.POINTER(RayLayer), _P, C.c_int, C.c_int, _P, _P, _P, _P]),
@@ -106,7 +108,7 @@ _SIGS = {
 }
 
 STAGES = ("sample", "project", "project_deep", "posenc", "rgbfeat", "view_attn", "ff", "qpos",
-          "ray_attn", "sem", "heads")
+          "ray_attn", "sem", "heads", "vis_order")
 
 EXPORTS = tuple(_SIGS)
 _lib = None

@@ -125,6 +125,95 @@ k_rgbfeat(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ rgb_feat
   }
 }
 
+// ------------------------------------------------------------------------------------ visibility order
+// Counting sort of the points by their set of visible views (bit v = mask[n][v] != 0; hashed to 12
+// bits when V > 12).  The order inside a bin is arbitrary: every point is computed independently of
+// its tile mates, so results do not depend on it.
+#define VIS_BINS 4096
+#define VIS_CHUNK 2048  // points per block
+
+__device__ __forceinline__ unsigned vis_bin(const float* __restrict__ mrow, int V) {
+  unsigned key = 0;
+  for (int v = 0; v < V; ++v) key |= (mrow[v] != 0.0f ? 1u : 0u) << v;
+  return V <= 12 ? key : ((key * 2654435761u) >> 20);
+}
+
+__global__ void __launch_bounds__(256)
+k_vis_hist(const float* __restrict__ mask, int N, int V, int* __restrict__ hist) {
+  __shared__ int lh[VIS_BINS];
+  for (int b = threadIdx.x; b < VIS_BINS; b += 256) lh[b] = 0;
+  __syncthreads();
+  const int n0 = blockIdx.x * VIS_CHUNK;
+  for (int i = threadIdx.x; i < VIS_CHUNK && n0 + i < N; i += 256)
+    atomicAdd(&lh[vis_bin(mask + (size_t)(n0 + i) * V, V)], 1);
+  __syncthreads();
+  for (int b = threadIdx.x; b < VIS_BINS; b += 256)
+    if (lh[b]) atomicAdd(&hist[b], lh[b]);
+}
+
+// Start offset of every bin.  Bins are laid out by decreasing cost class (number of views the tile
+// has to compute: popcount of the pattern, V for the all-masked pattern), so that the static
+// round-robin tile assignment of k_view_attn gives every wave the same mix of heavy and light tiles.
+__global__ void __launch_bounds__(1024)
+k_vis_scan(const int* __restrict__ hist, int* __restrict__ cursor, int V) {
+  __shared__ int part[1024];
+  __shared__ int running;
+  const int t = threadIdx.x;  // 4 bins per thread
+  int h[4], cls[4];
+  for (int k = 0; k < 4; ++k) {
+    const int b = 4 * t + k;
+    h[k] = hist[b];
+    cls[k] = V <= 12 ? (b == 0 ? V : __popc((unsigned)b)) : 0;
+  }
+  if (t == 0) running = 0;
+  __syncthreads();
+  for (int c = (V <= 12 ? V : 0); c >= 0; --c) {
+    int sum = 0;
+    for (int k = 0; k < 4; ++k) sum += cls[k] == c ? h[k] : 0;
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int add = t >= off ? part[t - off] : 0;
+      __syncthreads();
+      part[t] += add;
+      __syncthreads();
+    }
+    int base = running + part[t] - sum;
+    for (int k = 0; k < 4; ++k)
+      if (cls[k] == c) cursor[4 * t + k] = base, base += h[k];
+    __syncthreads();
+    if (t == 1023) running += part[1023];
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_vis_scatter(const float* __restrict__ mask, int N, int V, int* __restrict__ cursor,
+              int* __restrict__ perm) {
+  __shared__ int lh[VIS_BINS];
+  for (int b = threadIdx.x; b < VIS_BINS; b += 256) lh[b] = 0;
+  __syncthreads();
+  const int n0 = blockIdx.x * VIS_CHUNK;
+  int rank[VIS_CHUNK / 256];
+  unsigned bin[VIS_CHUNK / 256];
+#pragma unroll
+  for (int k = 0; k < VIS_CHUNK / 256; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    rank[k] = -1;
+    if (n0 + i < N) {
+      bin[k] = vis_bin(mask + (size_t)(n0 + i) * V, V);
+      rank[k] = atomicAdd(&lh[bin[k]], 1);
+    }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < VIS_BINS; b += 256)
+    if (lh[b]) lh[b] = atomicAdd(&cursor[b], lh[b]);  // this block's first slot in bin b
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < VIS_CHUNK / 256; ++k)
+    if (rank[k] >= 0) perm[lh[bin[k]] + rank[k]] = n0 + threadIdx.x + 256 * k;
+}
+
 // ------------------------------------------------------------------------------------ view attention
 // LDS image (floats):
 //   Wq, Wk, Wv, Wo [64][68] | pos2 [64][20] | attn0 [16][68] | attn2 [64][20] | pos0 [16][4]
@@ -156,8 +245,9 @@ constexpr int VIEW_LDS_FLOATS = 4 * 64 * LDW + 2 * 64 * VA_LD8 + 16 * LDW + 64 +
 
 __global__ void __launch_bounds__(512)
 k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __restrict__ feat,
-            const float* __restrict__ ray_diff, const float* __restrict__ mask, long long N, int V,
-            float* __restrict__ q_out, float* __restrict__ logits, float* __restrict__ stats) {
+            const float* __restrict__ ray_diff, const float* __restrict__ mask,
+            const int* __restrict__ perm, long long N, int V, float* __restrict__ q_out,
+            float* __restrict__ logits, float* __restrict__ stats) {
   const ViewLds L = view_lds(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   stage_matrix(L.Wq, LDW, Lw.q.w, 64, 64, tid, 512);
@@ -182,9 +272,13 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
   const long long ntiles = (N + 15) >> 4;
   for (long long tile = (long long)blockIdx.x * 8 + wave; tile < ntiles;
        tile += (long long)gridDim.x * 8) {
-    const long long n = tile * 16 + j;
-    const bool valid = n < N;
-    const long long nc = valid ? n : N - 1;
+    // slot -> point: identity, or the visibility-sorted order of gpn_vis_order (points with the
+    // same set of visible views share tiles, which makes the dead-view skip below effective)
+    const long long slot = tile * 16 + j;
+    const bool valid = slot < N;
+    const long long sc = valid ? slot : N - 1;
+    const long long n = perm != nullptr ? (long long)perm[sc] : sc;
+    const long long nc = n;
 
     f4 xq[4], qp[4];
 #pragma unroll
@@ -205,24 +299,33 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
     }
     // A masked view contributes exp(-1e9 - max) == 0 exactly as soon as the point has one visible
     // view, so a (tile, view) whose 16 points are all masked-but-visible-elsewhere is skipped whole.
-    bool any_vis = false;
-    for (int v = 0; v < V; ++v) any_vis |= mask[(size_t)nc * V + v] != 0.0f;
+    unsigned vis = 0;  // this point's visible views
+    for (int v = 0; v < V; ++v) vis |= (mask[(size_t)nc * V + v] != 0.0f ? 1u : 0u) << v;
+    // live views of the tile (wave-uniform): visible for some point, or needed by a point that has
+    // no visible view at all (its softmax is uniform over all V views)
+    unsigned live = 0;
+    {
+      const bool none = vis == 0;
+      for (int v = 0; v < V; ++v)
+        if (__any(none || ((vis >> v) & 1u))) live |= 1u << v;
+    }
+    live = __builtin_amdgcn_readfirstlane(live);
     const float* frow = feat + (size_t)nc * V * C64 + 4 * g;
     f4 fcur[4];
+    {
+      const int v0 = live ? __builtin_ctz(live) : 0;
 #pragma unroll
-    for (int T = 0; T < 4; ++T) fcur[T] = ld4(frow + 16 * T);
+      for (int T = 0; T < 4; ++T) fcur[T] = ld4(frow + (size_t)v0 * C64 + 16 * T);
+    }
 
-    for (int v = 0; v < V; ++v) {
-      f4 fnext[4];
-      const int vn = v + 1 < V ? v + 1 : v;
+    while (live) {
+      const int v = __builtin_ctz(live);
+      live &= live - 1;
+      f4 fnext[4];  // prefetch the next LIVE view while this one computes
+      const int vn = live ? __builtin_ctz(live) : v;
 #pragma unroll
       for (int T = 0; T < 4; ++T) fnext[T] = ld4(frow + (size_t)vn * C64 + 16 * T);
-      const float mk = mask[(size_t)nc * V + v];
-      if (__all((mk == 0.0f) && any_vis)) {  // wave-uniform
-#pragma unroll
-        for (int T = 0; T < 4; ++T) fcur[T] = fnext[T];
-        continue;
-      }
+      const float mk = (vis >> v) & 1u ? 1.0f : 0.0f;
       const float rd = ray_diff[((size_t)nc * V + v) * 4 + g];
 
       f4 k[4], val[4];
@@ -783,9 +886,31 @@ extern "C" int gpn_rgbfeat(const gpn_linear_t* fc0, const gpn_linear_t* fc2, con
   return GPN_OK;
 }
 
+extern "C" size_t gpn_vis_order_scratch_bytes(void) { return 2 * VIS_BINS * sizeof(int); }
+
+extern "C" int gpn_vis_order(const float* mask, int N, int V, int32_t* perm, void* scratch,
+                             gpn_stream_t stream) {
+  if (N == 0) return GPN_OK;
+  GPN_REQUIRE(mask && perm && scratch, "gpn_vis_order: null pointer");
+  GPN_REQUIRE(N > 0 && V >= 1 && V <= GPN_MAX_VIEWS, "gpn_vis_order: bad shape");
+  int* hist = static_cast<int*>(scratch);
+  int* cursor = hist + VIS_BINS;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(hist, 0, VIS_BINS * sizeof(int), st) != hipSuccess)
+    return gpn_set_error(GPN_E_LAUNCH, "gpn_vis_order: hipMemsetAsync failed");
+  const int blocks = gpn_ceil_div(N, VIS_CHUNK);
+  GpnStageTimer timer(GPN_ST_VIS_ORDER, st);
+  hipLaunchKernelGGL(k_vis_hist, dim3(blocks), dim3(256), 0, st, mask, N, V, hist);
+  hipLaunchKernelGGL(k_vis_scan, dim3(1), dim3(1024), 0, st, hist, cursor, V);
+  hipLaunchKernelGGL(k_vis_scatter, dim3(blocks), dim3(256), 0, st, mask, N, V, cursor, perm);
+  GPN_LAUNCH_CHECK("k_vis_order");
+  return GPN_OK;
+}
+
 extern "C" int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const float* feat,
-                             const float* ray_diff, const float* mask, int N, int V, float* q_out,
-                             float* logits, float* stats, gpn_stream_t stream) {
+                             const float* ray_diff, const float* mask, const int32_t* perm, int N,
+                             int V, float* q_out, float* logits, float* stats,
+                             gpn_stream_t stream) {
   if (N == 0) return GPN_OK;  // empty batch (pointers may be null)
   GPN_REQUIRE(L && q_in && feat && ray_diff && mask && q_out, "gpn_view_attn: null pointer");
   REQ_LIN(L->q, "gpn_view_attn.q");
@@ -805,7 +930,7 @@ extern "C" int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const
   const int grid = persistent_grid(((long long)N + 127) / 128);
   GpnStageTimer timer_k_view_attn_(GPN_ST_VIEW_ATTN, (hipStream_t)stream);
   hipLaunchKernelGGL(k_view_attn, dim3(grid), dim3(512), lds, (hipStream_t)stream, *L, q_in, feat,
-                     ray_diff, mask, (long long)N, V, q_out, logits, stats);
+                     ray_diff, mask, perm, (long long)N, V, q_out, logits, stats);
   GPN_LAUNCH_CHECK("k_view_attn");
   return GPN_OK;
 }
@@ -948,7 +1073,7 @@ extern "C" int gpn_heads(const gpn_gnt_weights_t* W, const float* q, const float
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct GntWs {
-  size_t emb, feat, q, logits, stats, abar, weights, pre, total;
+  size_t emb, feat, q, logits, stats, abar, weights, pre, perm, vis_scratch, total;
 };
 static GntWs gnt_ws_layout(int R, int S, int V, int depth) {
   const size_t N = (size_t)R * S, f = sizeof(float);
@@ -962,6 +1087,8 @@ static GntWs gnt_ws_layout(int R, int S, int V, int depth) {
   w.abar = o, o += depth * align_up((size_t)R * 4 * S * f);
   w.weights = o, o += align_up(N * f);
   w.pre = o, o += align_up((size_t)R * GPN_SEM * f);
+  w.perm = o, o += align_up(N * sizeof(int));
+  w.vis_scratch = o, o += align_up(2 * VIS_BINS * sizeof(int));
   w.total = o;
   return w;
 }
@@ -997,7 +1124,9 @@ extern "C" int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat
   float* q = reinterpret_cast<float*>(ws + L.q);
   float* wts = reinterpret_cast<float*>(ws + L.weights);
   float* pre = reinterpret_cast<float*>(ws + L.pre);
+  int32_t* perm = reinterpret_cast<int32_t*>(ws + L.perm);
   int rc;
+  if ((rc = gpn_vis_order(mask, (int)N, V, perm, ws + L.vis_scratch, stream))) return rc;
   if ((rc = gpn_posenc(pts, ray_d, R, S, emb, stream))) return rc;
   if ((rc = gpn_rgbfeat(&W->rgbfeat0, &W->rgbfeat2, rgb_feat, (int)N, V, 3 + W->in_feat_ch, feat, q,
                         stream)))
@@ -1008,7 +1137,7 @@ extern "C" int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat
     float* ab = sem ? reinterpret_cast<float*>(ws + L.abar + l * align_up((size_t)R * 4 * S * f)) : nullptr;
     const gpn_view_layer_t* vl = &W->view[l];
     const gpn_ray_layer_t* rl = &W->ray[l];
-    if ((rc = gpn_view_attn(vl, q, feat, ray_diff, mask, (int)N, V, q, lg, st, stream))) return rc;
+    if ((rc = gpn_view_attn(vl, q, feat, ray_diff, mask, perm, (int)N, V, q, lg, st, stream))) return rc;
     if ((rc = gpn_ff(vl->ff_norm_w, vl->ff_norm_b, &vl->ff1, &vl->ff2, q, (int)N, q, stream))) return rc;
     if (l % 2 == 0)
       if ((rc = gpn_qpos(&W->qfc0[l], &W->qfc2[l], q, emb, (int)N, q, stream))) return rc;

@@ -149,13 +149,21 @@ int gpn_rgbfeat(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* r
 
 /* Attention part of Transformer2D (attn_norm, Attention2D, residual), transformer_network.py:74-88
  * and :107-112.  q_in [N,C], feat [N,V,C], ray_diff [N,V,4], mask [N,V] -> q_out [N,C];
+ * perm [N] (or NULL): processing order from gpn_vis_order.
  * logits [N,V,C] = pre-softmax attention of the VISIBLE (point, view) pairs (mask != 0; entries of
  * masked pairs are left unwritten: their softmax weight is exactly 0, or exactly 1/V when the
  * point has no visible view at all); stats [N,2,C] = (max_v, 1/sum_v exp) so that the per-channel
  * view softmax of line :84 is exp(logit-max)*rsum. logits/stats may be NULL. */
 int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const float* feat,
-                  const float* ray_diff, const float* mask, int N, int V, float* q_out,
-                  float* logits, float* stats, gpn_stream_t stream);
+                  const float* ray_diff, const float* mask, const int32_t* perm, int N, int V,
+                  float* q_out, float* logits, float* stats, gpn_stream_t stream);
+
+/* No counterpart in the reference (scheduling aid for gpn_view_attn): perm [N] = the points sorted by
+ * their set of visible views, so that 16-point tiles are homogeneous and whole (tile, view) pairs
+ * can be skipped exactly.  perm == NULL in gpn_view_attn means identity; results are bit-identical
+ * either way.  scratch: gpn_vis_order_scratch_bytes() bytes of device memory. */
+size_t gpn_vis_order_scratch_bytes(void);
+int gpn_vis_order(const float* mask, int N, int V, int32_t* perm, void* scratch, gpn_stream_t stream);
 
 /* x + FeedForward(LayerNorm(x)), transformer_network.py:114-117 / :210-213 (eps 1e-6). x [N,C]. */
 int gpn_ff(const float* norm_w, const float* norm_b, const gpn_linear_t* fc1,
@@ -220,7 +228,7 @@ int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat, const flo
 enum {
   GPN_ST_SAMPLE = 0, GPN_ST_PROJECT, GPN_ST_PROJECT_DEEP, GPN_ST_POSENC, GPN_ST_RGBFEAT,
   GPN_ST_VIEW_ATTN, GPN_ST_FF, GPN_ST_QPOS, GPN_ST_RAY_ATTN, GPN_ST_SEM, GPN_ST_HEADS,
-  GPN_NSTAGES
+  GPN_ST_VIS_ORDER, GPN_NSTAGES
 };
 int gpn_timing_begin(unsigned stage_mask, int max_records);
 int gpn_timing_end(double* ms_per_stage, long long* launches_per_stage);

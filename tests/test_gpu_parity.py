@@ -265,8 +265,26 @@ def test_gnt_stages(dev, net, S):
         q_in = f((rec["q0"] if l == 0 else rec["q_ray"][l - 1]).reshape(N, 64))
         qo, lg, stt = e(N, 64), e(N, V, 64), e(N, 2, 64)
         _lib.check(L.gpn_view_attn(C.byref(W.view[l]), _lib.ptr(q_in), _lib.ptr(feat_ref), _lib.ptr(rd),
-                                   _lib.ptr(mk), N, V, _lib.ptr(qo), _lib.ptr(lg), _lib.ptr(stt), st), "view")
+                                   _lib.ptr(mk), None, N, V, _lib.ptr(qo), _lib.ptr(lg), _lib.ptr(stt), st), "view")
         errs["view_attn%d" % l] = rel(qo, rec["q_view_attn"][l].reshape(N, 64))
+        # same launch in visibility-sorted order: bit-identical outputs
+        perm = torch.empty(N, dtype=torch.int32, device=dev)
+        scr = torch.empty(L.gpn_vis_order_scratch_bytes(), dtype=torch.uint8, device=dev)
+        _lib.check(L.gpn_vis_order(_lib.ptr(mk), N, V, _lib.ptr(perm), _lib.ptr(scr), st), "vis_order")
+        assert torch.equal(torch.sort(perm.long())[0].cpu(), torch.arange(N)), "perm is not a permutation"
+        key = ((mk.reshape(N, V) != 0).long() << torch.arange(V, device=dev)).sum(-1)[perm.long()]
+        cost = torch.where(key == 0, torch.full_like(key, V), (mk.reshape(N, V) != 0).sum(-1)[perm.long()])
+        assert bool((cost[1:] <= cost[:-1]).all()), "perm is not ordered by decreasing cost class"
+        runs = int((key[1:] != key[:-1]).sum()) + 1
+        assert runs == int(torch.unique(key).numel()), "a visibility pattern is split across bins"
+        qo2, lg2, stt2 = e(N, 64), torch.zeros_like(lg), e(N, 2, 64)
+        lg.masked_fill_(mk.reshape(N, V, 1) == 0, 0.0)  # unwritten (masked) entries -> 0 on both sides
+        _lib.check(L.gpn_view_attn(C.byref(W.view[l]), _lib.ptr(q_in), _lib.ptr(feat_ref), _lib.ptr(rd),
+                                   _lib.ptr(mk), _lib.ptr(perm), N, V, _lib.ptr(qo2), _lib.ptr(lg2),
+                                   _lib.ptr(stt2), st), "view-perm")
+        lg2.masked_fill_(mk.reshape(N, V, 1) == 0, 0.0)
+        assert torch.equal(qo, qo2) and torch.equal(stt, stt2) and torch.equal(lg, lg2), \
+            "visibility-sorted order changed the results"
         # logits of masked pairs are never written: weight 0, or 1/V for an all-masked point
         vis = mk.reshape(N, V, 1) != 0
         attn = torch.where(vis, torch.exp(lg - stt[:, 0][:, None]) * stt[:, 1][:, None],

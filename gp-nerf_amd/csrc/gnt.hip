@@ -677,30 +677,39 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
 }
 
 // ------------------------------------------------------------------------------------ semantic aggregation
-// One workgroup (256 threads) per ray; thread (half, c4) owns deep channels c4..c4+3 of the samples
-// s = half (mod 2).  Per sample the softmax stats and abar of every layer are loaded once; per
-// visible (sample, view) the attention weights of every layer are rebuilt from the stored logits,
-// summed into W3d / W2d (per 8-channel group) and applied to the bilinearly sampled (or dense)
-// 512-ch deep-semantic row.  Masked views have weight exactly 0 and are skipped; a sample with no
-// visible view has the uniform weight 1/V in every layer (softmax of equal -1e9 logits).
-__global__ void __launch_bounds__(256)
+// One wave per ray, 8 adjacent rays per workgroup, lane = one 8-channel group of the 512 deep-semantic
+// channels (so the per-group attention weights are computed exactly once).  The 8 waves walk the
+// samples together (one barrier per sample): neighbouring rays project to neighbouring texels, so
+// their bilinear taps hit the same lines while those are still in L1/L2.  Per visible (sample, view)
+// the attention weights of every layer are rebuilt from the stored logits + softmax stats, summed
+// into W3d / W2d and applied to the sampled (or dense) deep-semantic row.  Masked views have weight
+// exactly 0 and are skipped; a sample with no visible view has the uniform weight 1/V in every layer.
+#define SEM_RAYS 8
+__global__ void __launch_bounds__(SEM_RAYS * 64, 4)
 k_sem(gpn_sem_args_t a) {
   __shared__ float sP[GPN_MAX_VIEWS * 12];
-  __shared__ __attribute__((aligned(16))) float sPre[512];
-  const int tid = threadIdx.x;
-  const int r = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2): give each XCD a
+  // contiguous run of ray groups.
+  int blk = blockIdx.x;
+  {
+    const int nb = gridDim.x, per = nb >> 3;
+    if (per > 0 && blk < per * 8) blk = (blk & 7) * per + (blk >> 3);
+  }
   const int S = a.S, V = a.V;
   if (a.deep_map != nullptr) {
-    for (int i = tid; i < V * 12; i += 256) sP[i] = a.proj[(i / 12) * 16 + (i % 12)];
+    for (int i = tid; i < V * 12; i += SEM_RAYS * 64) sP[i] = a.proj[(i / 12) * 16 + (i % 12)];
   }
   __syncthreads();
-  const int half = tid >> 7, lt = tid & 127;
-  const int c4 = lt * 4, grp = lt >> 1, head = grp >> 4;
-  f4 acc2 = f4_zero();
+  const int r = blk * SEM_RAYS + wave;
+  const bool rvalid = r < a.R;
+  const int rc = rvalid ? r : a.R - 1;
+  const int c8 = lane * 8, head = lane >> 4;  // lane == channel group
+  f4 acc2a = f4_zero(), acc2b = f4_zero();
   const size_t rs = (size_t)a.deep_w * GPN_SEM;
   const float inv_v = 1.0f / (float)V;
-  for (int s = half; s < S; s += 2) {
-    const size_t n = (size_t)r * S + s;
+  for (int s = 0; s < S; ++s) {
+    const size_t n = (size_t)rc * S + s;
     unsigned vis = 0;
     for (int v = 0; v < V; ++v) vis |= (a.mask[n * V + v] != 0.0f ? 1u : 0u) << v;
     float mx[GPN_MAX_DEPTH], rl[GPN_MAX_DEPTH], ab[GPN_MAX_DEPTH];
@@ -709,41 +718,47 @@ k_sem(gpn_sem_args_t a) {
     for (int l = 0; l < GPN_MAX_DEPTH; ++l) {
       mx[l] = rl[l] = ab[l] = 0.f;
       if (l < a.depth) {
-        ab[l] = a.abar[l][((size_t)r * 4 + head) * S + s];
+        ab[l] = a.abar[l][((size_t)rc * 4 + head) * S + s];
         if (vis != 0) {
-          mx[l] = a.stats[l][n * 128 + grp];
-          rl[l] = a.stats[l][n * 128 + 64 + grp];
+          mx[l] = a.stats[l][n * 128 + lane];
+          rl[l] = a.stats[l][n * 128 + 64 + lane];
         }
         w3u += inv_v;
         w2u += ab[l] * inv_v;
       }
     }
-    f4 acc3 = f4_zero();
+    f4 acc3a = f4_zero(), acc3b = f4_zero();
     float px = 0.f, py = 0.f, pz = 0.f;
     if (a.deep_map != nullptr) px = a.xyz[n * 3 + 0], py = a.xyz[n * 3 + 1], pz = a.xyz[n * 3 + 2];
-    for (int v = 0; v < V; ++v) {
-      if (vis != 0 && !((vis >> v) & 1u)) continue;  // softmax weight is exactly 0
-      // issue the deep-semantic loads first, the logits next; combine afterwards
-      f4 vnw = f4_zero(), vne = f4_zero(), vsw = f4_zero(), vse = f4_zero();
+    unsigned live = vis != 0 ? vis : (V >= 32 ? 0xffffffffu : ((1u << V) - 1u));
+    while (live) {
+      const int v = __builtin_ctz(live);
+      live &= live - 1;
+      f4 tnw[2], tne[2], tsw[2], tse[2];
       GpnTaps t;
       if (a.deep_dense != nullptr) {
-        vnw = ld4(a.deep_dense + (n * V + v) * GPN_SEM + c4);
+        tnw[0] = ld4(a.deep_dense + (n * V + v) * GPN_SEM + c8);
+        tnw[1] = ld4(a.deep_dense + (n * V + v) * GPN_SEM + c8 + 4);
       } else {
         const GpnPix pp = gpn_project(sP + v * 12, px, py, pz);
         t = gpn_taps(pp.px, pp.py, a.img_h, a.img_w, a.deep_h, a.deep_w);
-        const float* dm = a.deep_map + (size_t)v * a.deep_h * rs + c4;
+        const float* dm = a.deep_map + (size_t)v * a.deep_h * rs + c8;
         const size_t o00 = (size_t)t.y0 * rs + (size_t)t.x0 * GPN_SEM;
-        if (t.vy0 && t.vx0) vnw = ld4(dm + o00);
-        if (t.vy0 && t.vx1) vne = ld4(dm + o00 + GPN_SEM);
-        if (t.vy1 && t.vx0) vsw = ld4(dm + o00 + rs);
-        if (t.vy1 && t.vx1) vse = ld4(dm + o00 + rs + GPN_SEM);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          tnw[h] = tne[h] = tsw[h] = tse[h] = f4_zero();
+          if (t.vy0 && t.vx0) tnw[h] = ld4(dm + o00 + 4 * h);
+          if (t.vy0 && t.vx1) tne[h] = ld4(dm + o00 + GPN_SEM + 4 * h);
+          if (t.vy1 && t.vx0) tsw[h] = ld4(dm + o00 + rs + 4 * h);
+          if (t.vy1 && t.vx1) tse[h] = ld4(dm + o00 + rs + GPN_SEM + 4 * h);
+        }
       }
       float w3 = w3u, w2 = w2u;
       if (vis != 0) {
         float lg[GPN_MAX_DEPTH];
 #pragma unroll
         for (int l = 0; l < GPN_MAX_DEPTH; ++l)
-          lg[l] = l < a.depth ? a.logits[l][(n * V + v) * C64 + grp] : 0.f;
+          lg[l] = l < a.depth ? a.logits[l][(n * V + v) * C64 + lane] : 0.f;
         w3 = 0.f, w2 = 0.f;
 #pragma unroll
         for (int l = 0; l < GPN_MAX_DEPTH; ++l) {
@@ -754,21 +769,29 @@ k_sem(gpn_sem_args_t a) {
           }
         }
       }
-      f4 d = vnw;
+      f4 d0 = tnw[0], d1 = tnw[1];
       if (a.deep_dense == nullptr) {
-        d.x = gpn_bilerp(vnw.x, vne.x, vsw.x, vse.x, t);
-        d.y = gpn_bilerp(vnw.y, vne.y, vsw.y, vse.y, t);
-        d.z = gpn_bilerp(vnw.z, vne.z, vsw.z, vse.z, t);
-        d.w = gpn_bilerp(vnw.w, vne.w, vsw.w, vse.w, t);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          d0[c] = gpn_bilerp(tnw[0][c], tne[0][c], tsw[0][c], tse[0][c], t);
+          d1[c] = gpn_bilerp(tnw[1][c], tne[1][c], tsw[1][c], tse[1][c], t);
+        }
       }
-      acc3 = acc3 + d * f4_splat(w3);
-      acc2 = acc2 + d * f4_splat(w2);
+      acc3a = acc3a + d0 * f4_splat(w3);
+      acc3b = acc3b + d1 * f4_splat(w3);
+      acc2a = acc2a + d0 * f4_splat(w2);
+      acc2b = acc2b + d1 * f4_splat(w2);
     }
-    if (a.sem3d != nullptr) st4(a.sem3d + n * GPN_SEM + c4, acc3);
+    if (a.sem3d != nullptr && rvalid) {
+      st4(a.sem3d + n * GPN_SEM + c8, acc3a);
+      st4(a.sem3d + n * GPN_SEM + c8 + 4, acc3b);
+    }
+    __syncthreads();  // keep the 8 rays of the group on the same sample (cache locality only)
   }
-  if (half == 1) st4(sPre + c4, acc2);
-  __syncthreads();
-  if (half == 0) st4(a.pre + (size_t)r * GPN_SEM + c4, acc2 + ld4(sPre + c4));
+  if (rvalid) {
+    st4(a.pre + (size_t)r * GPN_SEM + c8, acc2a);
+    st4(a.pre + (size_t)r * GPN_SEM + c8 + 4, acc2b);
+  }
 }
 
 // ------------------------------------------------------------------------------------ heads
@@ -1038,7 +1061,8 @@ extern "C" int gpn_sem_aggregate(const gpn_sem_args_t* a, gpn_stream_t stream) {
   GPN_REQUIRE(aligned16(a->pre) && aligned16(a->sem3d), "gpn_sem_aggregate: outputs must be aligned");
   if (a->R == 0) return GPN_OK;
   GpnStageTimer timer_k_sem_(GPN_ST_SEM, (hipStream_t)stream);
-  hipLaunchKernelGGL(k_sem, dim3(a->R), dim3(256), 0, (hipStream_t)stream, *a);
+  hipLaunchKernelGGL(k_sem, dim3(gpn_ceil_div(a->R, SEM_RAYS)), dim3(SEM_RAYS * 64), 0,
+                     (hipStream_t)stream, *a);
   GPN_LAUNCH_CHECK("k_sem");
   return GPN_OK;
 }

@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgpnerf_hip.so")
+# GPN_LIB: developer override used to A/B kernel build variants; the default is the in-tree library
+LIB_PATH = os.environ.get("GPN_LIB") or os.path.join(_HERE, "csrc", "libgpnerf_hip.so")
 
 MAX_DEPTH = 8
 MAX_VIEWS = 32

@@ -15,6 +15,19 @@
 #include "proj_common.h"
 
 #define C64 64
+// threads per workgroup of the persistent per-point kernels (one 16-point tile per wave)
+#ifndef RF_TPB
+#define RF_TPB 512
+#endif
+#ifndef VA_TPB
+#define VA_TPB 512
+#endif
+#ifndef FF_TPB
+#define FF_TPB 512
+#endif
+#ifndef QP_TPB
+#define QP_TPB 512
+#endif
 #define LDW 68  // padded leading dimension of a 64-wide weight matrix in LDS
 
 extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -68,7 +81,7 @@ __global__ void k_posenc(const float* __restrict__ pts, const float* __restrict_
 // ------------------------------------------------------------------------------------ rgbfeat
 // LDS: W0 [64][52] (in_ch zero-padded to 48), W2 [64][68], b0 [64], b2 [64]
 #define RF_LD0 52
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(RF_TPB)
 k_rgbfeat(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ rgb_feat, long long N, int V,
           int in_ch, float* __restrict__ feat, float* __restrict__ q0) {
   float* W0 = smem;
@@ -76,15 +89,15 @@ k_rgbfeat(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ rgb_feat
   float* b0 = W2 + 64 * LDW;
   float* b2 = b0 + 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  stage_padded(W0, RF_LD0, 64, 48, fc0.w, 64, in_ch, tid, 512);
-  stage_matrix(W2, LDW, fc2.w, 64, 64, tid, 512);
-  stage_vector(b0, 64, fc0.b, 64, tid, 512);
-  stage_vector(b2, 64, fc2.b, 64, tid, 512);
+  stage_padded(W0, RF_LD0, 64, 48, fc0.w, 64, in_ch, tid, RF_TPB);
+  stage_matrix(W2, LDW, fc2.w, 64, 64, tid, RF_TPB);
+  stage_vector(b0, 64, fc0.b, 64, tid, RF_TPB);
+  stage_vector(b2, 64, fc2.b, 64, tid, RF_TPB);
   __syncthreads();
   const int j = lane & 15, g = lane >> 4;
   const long long ntiles = (N + 15) >> 4;
-  for (long long tile = (long long)blockIdx.x * 8 + wave; tile < ntiles;
-       tile += (long long)gridDim.x * 8) {
+  for (long long tile = (long long)blockIdx.x * (RF_TPB / 64) + wave; tile < ntiles;
+       tile += (long long)gridDim.x * (RF_TPB / 64)) {
     const long long n = tile * 16 + j;
     const bool valid = n < N;
     const long long nc = valid ? n : N - 1;
@@ -243,35 +256,35 @@ __device__ __forceinline__ ViewLds view_lds(float* s) {
 }
 constexpr int VIEW_LDS_FLOATS = 4 * 64 * LDW + 2 * 64 * VA_LD8 + 16 * LDW + 64 + 16 + 64 + 16 + 64 * 4;
 
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(VA_TPB)
 k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __restrict__ feat,
             const float* __restrict__ ray_diff, const float* __restrict__ mask,
             const int* __restrict__ perm, long long N, int V, float* __restrict__ q_out,
             float* __restrict__ logits, float* __restrict__ stats) {
   const ViewLds L = view_lds(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  stage_matrix(L.Wq, LDW, Lw.q.w, 64, 64, tid, 512);
-  stage_matrix(L.Wk, LDW, Lw.k.w, 64, 64, tid, 512);
-  stage_matrix(L.Wv, LDW, Lw.v.w, 64, 64, tid, 512);
-  stage_matrix(L.Wo, LDW, Lw.out.w, 64, 64, tid, 512);
-  stage_padded(L.P2, VA_LD8, 64, 16, Lw.pos2.w, 64, 8, tid, 512);
-  stage_padded(L.A0, LDW, 16, 64, Lw.attn0.w, 8, 64, tid, 512);
-  stage_padded(L.A2, VA_LD8, 64, 16, Lw.attn2.w, 64, 8, tid, 512);
-  stage_padded(L.P0, 4, 16, 4, Lw.pos0.w, 8, 4, tid, 512);
-  stage_vector(L.bP0, 16, Lw.pos0.b, 8, tid, 512);
-  stage_vector(L.bP2, 64, Lw.pos2.b, 64, tid, 512);
-  stage_vector(L.bA0, 16, Lw.attn0.b, 8, tid, 512);
-  stage_vector(L.bA2, 64, Lw.attn2.b, 64, tid, 512);
-  stage_vector(L.bO, 64, Lw.out.b, 64, tid, 512);
-  stage_vector(L.gam, 64, Lw.attn_norm_w, 64, tid, 512);
-  stage_vector(L.bet, 64, Lw.attn_norm_b, 64, tid, 512);
+  stage_matrix(L.Wq, LDW, Lw.q.w, 64, 64, tid, VA_TPB);
+  stage_matrix(L.Wk, LDW, Lw.k.w, 64, 64, tid, VA_TPB);
+  stage_matrix(L.Wv, LDW, Lw.v.w, 64, 64, tid, VA_TPB);
+  stage_matrix(L.Wo, LDW, Lw.out.w, 64, 64, tid, VA_TPB);
+  stage_padded(L.P2, VA_LD8, 64, 16, Lw.pos2.w, 64, 8, tid, VA_TPB);
+  stage_padded(L.A0, LDW, 16, 64, Lw.attn0.w, 8, 64, tid, VA_TPB);
+  stage_padded(L.A2, VA_LD8, 64, 16, Lw.attn2.w, 64, 8, tid, VA_TPB);
+  stage_padded(L.P0, 4, 16, 4, Lw.pos0.w, 8, 4, tid, VA_TPB);
+  stage_vector(L.bP0, 16, Lw.pos0.b, 8, tid, VA_TPB);
+  stage_vector(L.bP2, 64, Lw.pos2.b, 64, tid, VA_TPB);
+  stage_vector(L.bA0, 16, Lw.attn0.b, 8, tid, VA_TPB);
+  stage_vector(L.bA2, 64, Lw.attn2.b, 64, tid, VA_TPB);
+  stage_vector(L.bO, 64, Lw.out.b, 64, tid, VA_TPB);
+  stage_vector(L.gam, 64, Lw.attn_norm_w, 64, tid, VA_TPB);
+  stage_vector(L.bet, 64, Lw.attn_norm_b, 64, tid, VA_TPB);
   __syncthreads();
 
   const int j = lane & 15, g = lane >> 4;
   const float p0w = L.P0[j * 4 + g];  // A operand of the 4 -> 8 layer: W[i = j][k = g]
   const long long ntiles = (N + 15) >> 4;
-  for (long long tile = (long long)blockIdx.x * 8 + wave; tile < ntiles;
-       tile += (long long)gridDim.x * 8) {
+  for (long long tile = (long long)blockIdx.x * (VA_TPB / 64) + wave; tile < ntiles;
+       tile += (long long)gridDim.x * (VA_TPB / 64)) {
     // slot -> point: identity, or the visibility-sorted order of gpn_vis_order (points with the
     // same set of visible views share tiles, which makes the dead-view skip below effective)
     const long long slot = tile * 16 + j;
@@ -403,7 +416,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
 #define FF_LD2 260
 constexpr int FF_LDS_FLOATS = 256 * LDW + 64 * FF_LD2 + 256 + 64 * 3;
 
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(FF_TPB)
 k_ff(const float* __restrict__ norm_w, const float* __restrict__ norm_b, gpn_linear_t fc1,
      gpn_linear_t fc2, const float* __restrict__ x_in, long long N, float* __restrict__ x_out) {
   float* W1 = smem;
@@ -413,17 +426,17 @@ k_ff(const float* __restrict__ norm_w, const float* __restrict__ norm_b, gpn_lin
   float* gam = b2 + 64;
   float* bet = gam + 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  stage_matrix(W1, LDW, fc1.w, 256, 64, tid, 512);
-  stage_matrix(W2, FF_LD2, fc2.w, 64, 256, tid, 512);
-  stage_vector(b1, 256, fc1.b, 256, tid, 512);
-  stage_vector(b2, 64, fc2.b, 64, tid, 512);
-  stage_vector(gam, 64, norm_w, 64, tid, 512);
-  stage_vector(bet, 64, norm_b, 64, tid, 512);
+  stage_matrix(W1, LDW, fc1.w, 256, 64, tid, FF_TPB);
+  stage_matrix(W2, FF_LD2, fc2.w, 64, 256, tid, FF_TPB);
+  stage_vector(b1, 256, fc1.b, 256, tid, FF_TPB);
+  stage_vector(b2, 64, fc2.b, 64, tid, FF_TPB);
+  stage_vector(gam, 64, norm_w, 64, tid, FF_TPB);
+  stage_vector(bet, 64, norm_b, 64, tid, FF_TPB);
   __syncthreads();
   const int j = lane & 15, g = lane >> 4;
   const long long ntiles = (N + 15) >> 4;
-  for (long long tile = (long long)blockIdx.x * 8 + wave; tile < ntiles;
-       tile += (long long)gridDim.x * 8) {
+  for (long long tile = (long long)blockIdx.x * (FF_TPB / 64) + wave; tile < ntiles;
+       tile += (long long)gridDim.x * (FF_TPB / 64)) {
     const long long n = tile * 16 + j;
     const bool valid = n < N;
     const long long nc = valid ? n : N - 1;
@@ -451,7 +464,7 @@ k_ff(const float* __restrict__ norm_w, const float* __restrict__ norm_b, gpn_lin
 #define QP_LD0 196
 constexpr int QP_LDS_FLOATS = 64 * QP_LD0 + 64 * LDW + 128;
 
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(QP_TPB)
 k_qpos(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ q_in,
        const float* __restrict__ emb, long long N, float* __restrict__ q_out) {
   float* W0 = smem;
@@ -459,15 +472,15 @@ k_qpos(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ q_in,
   float* b0 = W2 + 64 * LDW;
   float* b2 = b0 + 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  stage_padded(W0, QP_LD0, 64, 192, fc0.w, 64, 190, tid, 512);
-  stage_matrix(W2, LDW, fc2.w, 64, 64, tid, 512);
-  stage_vector(b0, 64, fc0.b, 64, tid, 512);
-  stage_vector(b2, 64, fc2.b, 64, tid, 512);
+  stage_padded(W0, QP_LD0, 64, 192, fc0.w, 64, 190, tid, QP_TPB);
+  stage_matrix(W2, LDW, fc2.w, 64, 64, tid, QP_TPB);
+  stage_vector(b0, 64, fc0.b, 64, tid, QP_TPB);
+  stage_vector(b2, 64, fc2.b, 64, tid, QP_TPB);
   __syncthreads();
   const int j = lane & 15, g = lane >> 4;
   const long long ntiles = (N + 15) >> 4;
-  for (long long tile = (long long)blockIdx.x * 8 + wave; tile < ntiles;
-       tile += (long long)gridDim.x * 8) {
+  for (long long tile = (long long)blockIdx.x * (QP_TPB / 64) + wave; tile < ntiles;
+       tile += (long long)gridDim.x * (QP_TPB / 64)) {
     const long long n = tile * 16 + j;
     const bool valid = n < N;
     const long long nc = valid ? n : N - 1;
@@ -542,14 +555,25 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
   const int sqc = qvalid ? sq : S - 1;
   const float qsel = qvalid ? 1.0f : 0.0f;
 
+  f4 xpre[4];  // next iteration's input tile, loaded one iteration ahead
+  {
+    const int r0 = blockIdx.x * RPW + slot;
+    const size_t row0 = ((size_t)(r0 < R ? r0 : R - 1) * S + sqc) * C64;
+#pragma unroll
+    for (int T = 0; T < 4; ++T) xpre[T] = ld4(x_in + row0 + 16 * T + 4 * g);
+  }
   for (int grp = blockIdx.x; grp * RPW < R; grp += gridDim.x) {
     const int ray = grp * RPW + slot;
     const bool valid = ray < R;
-    const int rc = valid ? ray : R - 1;
-    const size_t row = ((size_t)rc * S + sqc) * C64;
     f4 x[4], xn[4], qT[4];
 #pragma unroll
-    for (int T = 0; T < 4; ++T) x[T] = ld4(x_in + row + 16 * T + 4 * g);
+    for (int T = 0; T < 4; ++T) x[T] = xpre[T];
+    {
+      const int rn = (grp + (int)gridDim.x) * RPW + slot;
+      const size_t rown = ((size_t)(rn < R ? rn : R - 1) * S + sqc) * C64;
+#pragma unroll
+      for (int T = 0; T < 4; ++T) xpre[T] = ld4(x_in + rown + 16 * T + 4 * g);
+    }
     layernorm_T(x, xn, gam, bet, 1e-6f, lane);
 #pragma unroll
     for (int M = 0; M < 4; ++M) qT[M] = f4_zero();
@@ -619,12 +643,8 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
         if (t == 0) wacc[kt] = wacc[kt] + sT[kt];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float c = sT[kt][r] * qsel;
-          c += __shfl_xor(c, 1);
-          c += __shfl_xor(c, 2);
-          c += __shfl_xor(c, 4);
-          c += __shfl_xor(c, 8);
-          if (j == 0) part[((slot * NT + t) * 4 + h) * SP + 16 * kt + 4 * g + r] = c;
+          const float c = row_sum16(sT[kt][r] * qsel);  // total in lane 15 of each 16-lane row
+          if (j == 15) part[((slot * NT + t) * 4 + h) * SP + 16 * kt + 4 * g + r] = c;
         }
       }
       // O^T[h] = V_h^T . P^T : A = V (channels of head h on rows), B = P^T (keys in registers)
@@ -672,7 +692,8 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
         if (rr < R && key < S) abar[((size_t)rr * 4 + h) * S + key] = c / (float)S;
       }
     }
-    __syncthreads();
+    // no third barrier: the next iteration writes Ks / Vt only (every wave is past the attention
+    // phase here) and its own barrier separates these reads of `part` from the next writes to it
   }
 }
 
@@ -901,9 +922,9 @@ extern "C" int gpn_rgbfeat(const gpn_linear_t* fc0, const gpn_linear_t* fc2, con
   GPN_REQUIRE(aligned16(feat) && aligned16(q0), "gpn_rgbfeat: outputs must be 16-byte aligned");
   if (N == 0) return GPN_OK;
   const size_t lds = sizeof(float) * (64 * RF_LD0 + 64 * LDW + 128);
-  const int grid = persistent_grid(((long long)N + 127) / 128);
+  const int grid = persistent_grid(((long long)N + (RF_TPB / 4) - 1) / (RF_TPB / 4));
   GpnStageTimer timer_k_rgbfeat_(GPN_ST_RGBFEAT, (hipStream_t)stream);
-  hipLaunchKernelGGL(k_rgbfeat, dim3(grid), dim3(512), lds, (hipStream_t)stream, *fc0, *fc2,
+  hipLaunchKernelGGL(k_rgbfeat, dim3(grid), dim3(RF_TPB), lds, (hipStream_t)stream, *fc0, *fc2,
                      rgb_feat, (long long)N, V, in_ch, feat, q0);
   GPN_LAUNCH_CHECK("k_rgbfeat");
   return GPN_OK;
@@ -950,9 +971,9 @@ extern "C" int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const
   const size_t lds = sizeof(float) * VIEW_LDS_FLOATS;
   int rc = set_lds_limit(reinterpret_cast<const void*>(k_view_attn), lds);
   if (rc) return rc;
-  const int grid = persistent_grid(((long long)N + 127) / 128);
+  const int grid = persistent_grid(((long long)N + (VA_TPB / 4) - 1) / (VA_TPB / 4));
   GpnStageTimer timer_k_view_attn_(GPN_ST_VIEW_ATTN, (hipStream_t)stream);
-  hipLaunchKernelGGL(k_view_attn, dim3(grid), dim3(512), lds, (hipStream_t)stream, *L, q_in, feat,
+  hipLaunchKernelGGL(k_view_attn, dim3(grid), dim3(VA_TPB), lds, (hipStream_t)stream, *L, q_in, feat,
                      ray_diff, mask, perm, (long long)N, V, q_out, logits, stats);
   GPN_LAUNCH_CHECK("k_view_attn");
   return GPN_OK;
@@ -971,9 +992,9 @@ extern "C" int gpn_ff(const float* norm_w, const float* norm_b, const gpn_linear
   const size_t lds = sizeof(float) * FF_LDS_FLOATS;
   int rc = set_lds_limit(reinterpret_cast<const void*>(k_ff), lds);
   if (rc) return rc;
-  const int grid = persistent_grid(((long long)N + 127) / 128);
+  const int grid = persistent_grid(((long long)N + (FF_TPB / 4) - 1) / (FF_TPB / 4));
   GpnStageTimer timer_k_ff_(GPN_ST_FF, (hipStream_t)stream);
-  hipLaunchKernelGGL(k_ff, dim3(grid), dim3(512), lds, (hipStream_t)stream, norm_w, norm_b, *fc1,
+  hipLaunchKernelGGL(k_ff, dim3(grid), dim3(FF_TPB), lds, (hipStream_t)stream, norm_w, norm_b, *fc1,
                      *fc2, x_in, (long long)N, x_out);
   GPN_LAUNCH_CHECK("k_ff");
   return GPN_OK;
@@ -992,9 +1013,9 @@ extern "C" int gpn_qpos(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const 
   const size_t lds = sizeof(float) * QP_LDS_FLOATS;
   int rc = set_lds_limit(reinterpret_cast<const void*>(k_qpos), lds);
   if (rc) return rc;
-  const int grid = persistent_grid(((long long)N + 127) / 128);
+  const int grid = persistent_grid(((long long)N + (QP_TPB / 4) - 1) / (QP_TPB / 4));
   GpnStageTimer timer_k_qpos_(GPN_ST_QPOS, (hipStream_t)stream);
-  hipLaunchKernelGGL(k_qpos, dim3(grid), dim3(512), lds, (hipStream_t)stream, *fc0, *fc2, q_in, emb,
+  hipLaunchKernelGGL(k_qpos, dim3(grid), dim3(QP_TPB), lds, (hipStream_t)stream, *fc0, *fc2, q_in, emb,
                      (long long)N, q_out);
   GPN_LAUNCH_CHECK("k_qpos");
   return GPN_OK;

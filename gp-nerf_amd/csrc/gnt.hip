@@ -511,12 +511,15 @@ k_qpos(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ q_in,
 //      | part [RPW][NT][4][S]   (per-wave column sums of A, reduced in fixed order)
 template <int NT>
 struct RayCfg {
-  static constexpr int RPW = NT <= 4 ? 2 : 1;
+  // rays per workgroup (3 rays for NT == 3 fits LDS but measured 5 % slower: uneven iteration count)
+  static constexpr int RPW = NT <= 2 ? 4 : (NT <= 4 ? 2 : 1);
   static constexpr int SP = NT * 16;  // samples per ray, padded to whole 16-sample tiles
   static constexpr int LDV = SP + 4;
   static constexpr int THREADS = RPW * NT * 64;
   static constexpr int LDS_FLOATS =
       4 * 64 * LDW + 3 * 64 + RPW * SP * LDW + RPW * 64 * LDV + RPW * NT * 4 * SP;
+  static_assert(LDS_FLOATS * 4 <= 160 * 1024, "ray attention LDS image exceeds 160 KiB");
+  static_assert(THREADS <= 1024, "too many waves per workgroup");
 };
 
 template <int NT>

@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-rays", type=int, default=1536, help="rays of the CPU baseline sample (0: skip)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-stage time table to stderr")
+    ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16x3"),
+                    help="arithmetic of the GNT linear layers (see include/gpnerf_hip.h)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,6 +130,7 @@ def main():
     from gp_nerf_amd.render_ray import render_rays
     _lib.lib()
     scene, net, projector = build(dev)
+    net.precision = a.precision
     model = types.SimpleNamespace(net_coarse=net, net_fine=None)
     rb = ray_chunk(scene, rank, world, dev)
     tile_w = 2 * (3 + 1 + 512)

@@ -104,6 +104,8 @@ _SIGS = {
     "gpn_gnt_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "gpn_gnt_forward": (C.c_int, [C.POINTER(GntWeights), _P, _P, _P, _P, _P, _P, C.c_int, C.c_int,
                                   C.c_int, C.POINTER(SemArgs), _P, _P, _P, _P, C.c_size_t, _P]),
+    "gpn_set_precision": (C.c_int, [C.c_int]),
+    "gpn_get_precision": (C.c_int, []),
     "gpn_timing_begin": (C.c_int, [C.c_uint, C.c_int]),
     "gpn_timing_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
 }
@@ -190,3 +192,16 @@ class stage_timing:
         self.ms = {s: ms[i] for i, s in enumerate(STAGES)}
         self.launches = {s: cnt[i] for i, s in enumerate(STAGES)}
         return False
+
+
+PRECISIONS = {"fp32": 0, "bf16x3": 1}
+
+
+def set_precision(mode):
+    """'fp32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 MFMA, fp32 accumulate; see the header)."""
+    check(lib().gpn_set_precision(PRECISIONS[mode]), "gpn_set_precision")
+
+
+def get_precision():
+    code = lib().gpn_get_precision()
+    return [k for k, v in PRECISIONS.items() if v == code][0]

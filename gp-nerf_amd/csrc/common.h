@@ -36,3 +36,6 @@ class GpnStageTimer {
   int slot_;
   hipStream_t stream_;
 };
+
+// Arithmetic mode of the GNT linear layers (gpn_set_precision in the header).
+int gpn_precision();

@@ -89,3 +89,13 @@ extern "C" int gpn_timing_end(double* ms_per_stage, long long* launches_per_stag
   g_used = 0;
   return rc;
 }
+
+// ---------------------------------------------------------------- precision mode
+static int g_precision = GPN_PREC_FP32;
+int gpn_precision() { return g_precision; }
+extern "C" int gpn_get_precision(void) { return g_precision; }
+extern "C" int gpn_set_precision(int mode) {
+  GPN_REQUIRE(mode == GPN_PREC_FP32 || mode == GPN_PREC_BF16X3, "gpn_set_precision: unknown mode %d", mode);
+  g_precision = mode;
+  return GPN_OK;
+}

@@ -81,16 +81,17 @@ __global__ void k_posenc(const float* __restrict__ pts, const float* __restrict_
 // ------------------------------------------------------------------------------------ rgbfeat
 // LDS: W0 [64][52] (in_ch zero-padded to 48), W2 [64][68], b0 [64], b2 [64]
 #define RF_LD0 52
+template <bool SPL>
 __global__ void __launch_bounds__(RF_TPB)
 k_rgbfeat(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ rgb_feat, long long N, int V,
           int in_ch, float* __restrict__ feat, float* __restrict__ q0) {
   float* W0 = smem;
-  float* W2 = W0 + 64 * RF_LD0;
-  float* b0 = W2 + 64 * LDW;
+  float* W2 = W0 + wimg_floats(SPL, 64, 3, RF_LD0);
+  float* b0 = W2 + wimg_floats(SPL, 64, 4, LDW);
   float* b2 = b0 + 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  stage_padded(W0, RF_LD0, 64, 48, fc0.w, 64, in_ch, tid, RF_TPB);
-  stage_matrix(W2, LDW, fc2.w, 64, 64, tid, RF_TPB);
+  stage_w<SPL>(W0, RF_LD0, fc0.w, 64, in_ch, 64, 3, tid, RF_TPB);
+  stage_w<SPL>(W2, LDW, fc2.w, 64, 64, 64, 4, tid, RF_TPB);
   stage_vector(b0, 64, fc0.b, 64, tid, RF_TPB);
   stage_vector(b2, 64, fc2.b, 64, tid, RF_TPB);
   __syncthreads();
@@ -117,13 +118,13 @@ k_rgbfeat(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ rgb_feat
       f4 h[4], y[4];
 #pragma unroll
       for (int M = 0; M < 4; ++M) h[M] = ld4(b0 + 16 * M + 4 * g);
-      lin_T<3, 4>(W0, RF_LD0, x, h, lane);
+      lin<SPL, 3, 4>(W0, RF_LD0, x, h, lane);
 #pragma unroll
       for (int M = 0; M < 4; ++M) {
         h[M] = f4_relu(h[M]);
         y[M] = ld4(b2 + 16 * M + 4 * g);
       }
-      lin_T<4, 4>(W2, LDW, h, y, lane);
+      lin<SPL, 4, 4>(W2, LDW, h, y, lane);
       float* out = feat + ((size_t)nc * V + v) * C64 + 4 * g;
 #pragma unroll
       for (int M = 0; M < 4; ++M) {
@@ -235,16 +236,17 @@ k_vis_scatter(const float* __restrict__ mask, int N, int V, int* __restrict__ cu
 struct ViewLds {
   float *Wq, *Wk, *Wv, *Wo, *P2, *A0, *A2, *P0, *bP0, *bP2, *bA0, *bA2, *bO, *gam, *bet;
 };
+template <bool SPL>
 __device__ __forceinline__ ViewLds view_lds(float* s) {
   ViewLds L;
   L.Wq = s;
-  L.Wk = L.Wq + 64 * LDW;
-  L.Wv = L.Wk + 64 * LDW;
-  L.Wo = L.Wv + 64 * LDW;
-  L.P2 = L.Wo + 64 * LDW;
-  L.A0 = L.P2 + 64 * VA_LD8;
-  L.A2 = L.A0 + 16 * LDW;
-  L.P0 = L.A2 + 64 * VA_LD8;
+  L.Wk = L.Wq + wimg_floats(SPL, 64, 4, LDW);
+  L.Wv = L.Wk + wimg_floats(SPL, 64, 4, LDW);
+  L.Wo = L.Wv + wimg_floats(SPL, 64, 4, LDW);
+  L.P2 = L.Wo + wimg_floats(SPL, 64, 4, LDW);
+  L.A0 = L.P2 + wimg_floats(SPL, 64, 1, VA_LD8);
+  L.A2 = L.A0 + wimg_floats(SPL, 16, 4, LDW);
+  L.P0 = L.A2 + wimg_floats(SPL, 64, 1, VA_LD8);
   L.bP0 = L.P0 + 64;
   L.bP2 = L.bP0 + 16;
   L.bA0 = L.bP2 + 64;
@@ -254,22 +256,26 @@ __device__ __forceinline__ ViewLds view_lds(float* s) {
   L.bet = L.gam + 64;
   return L;
 }
-constexpr int VIEW_LDS_FLOATS = 4 * 64 * LDW + 2 * 64 * VA_LD8 + 16 * LDW + 64 + 16 + 64 + 16 + 64 * 4;
+constexpr int view_lds_floats(bool spl) {
+  return 4 * wimg_floats(spl, 64, 4, LDW) + 2 * wimg_floats(spl, 64, 1, VA_LD8) +
+         wimg_floats(spl, 16, 4, LDW) + 64 + 16 + 64 + 16 + 64 * 4;
+}
 
+template <bool SPL>
 __global__ void __launch_bounds__(VA_TPB)
 k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __restrict__ feat,
             const float* __restrict__ ray_diff, const float* __restrict__ mask,
             const int* __restrict__ perm, long long N, int V, float* __restrict__ q_out,
             float* __restrict__ logits, float* __restrict__ stats) {
-  const ViewLds L = view_lds(smem);
+  const ViewLds L = view_lds<SPL>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  stage_matrix(L.Wq, LDW, Lw.q.w, 64, 64, tid, VA_TPB);
-  stage_matrix(L.Wk, LDW, Lw.k.w, 64, 64, tid, VA_TPB);
-  stage_matrix(L.Wv, LDW, Lw.v.w, 64, 64, tid, VA_TPB);
-  stage_matrix(L.Wo, LDW, Lw.out.w, 64, 64, tid, VA_TPB);
-  stage_padded(L.P2, VA_LD8, 64, 16, Lw.pos2.w, 64, 8, tid, VA_TPB);
-  stage_padded(L.A0, LDW, 16, 64, Lw.attn0.w, 8, 64, tid, VA_TPB);
-  stage_padded(L.A2, VA_LD8, 64, 16, Lw.attn2.w, 64, 8, tid, VA_TPB);
+  stage_w<SPL>(L.Wq, LDW, Lw.q.w, 64, 64, 64, 4, tid, VA_TPB);
+  stage_w<SPL>(L.Wk, LDW, Lw.k.w, 64, 64, 64, 4, tid, VA_TPB);
+  stage_w<SPL>(L.Wv, LDW, Lw.v.w, 64, 64, 64, 4, tid, VA_TPB);
+  stage_w<SPL>(L.Wo, LDW, Lw.out.w, 64, 64, 64, 4, tid, VA_TPB);
+  stage_w<SPL>(L.P2, VA_LD8, Lw.pos2.w, 64, 8, 64, 1, tid, VA_TPB);
+  stage_w<SPL>(L.A0, LDW, Lw.attn0.w, 8, 64, 16, 4, tid, VA_TPB);
+  stage_w<SPL>(L.A2, VA_LD8, Lw.attn2.w, 64, 8, 64, 1, tid, VA_TPB);
   stage_padded(L.P0, 4, 16, 4, Lw.pos0.w, 8, 4, tid, VA_TPB);
   stage_vector(L.bP0, 16, Lw.pos0.b, 8, tid, VA_TPB);
   stage_vector(L.bP2, 64, Lw.pos2.b, 64, tid, VA_TPB);
@@ -301,7 +307,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
       layernorm_T(xq, qn, L.gam, L.bet, 1e-6f, lane);
 #pragma unroll
       for (int M = 0; M < 4; ++M) qp[M] = f4_zero();
-      lin_T<4, 4>(L.Wq, LDW, qn, qp, lane);
+      lin<SPL, 4, 4>(L.Wq, LDW, qn, qp, lane);
     }
     f4 mrun[4], lrun[4], acc[4];
 #pragma unroll
@@ -344,26 +350,26 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
       f4 k[4], val[4];
 #pragma unroll
       for (int M = 0; M < 4; ++M) k[M] = f4_zero(), val[M] = f4_zero();
-      lin_T<4, 4>(L.Wk, LDW, fcur, k, lane);   // k = k_fc(feat)
-      lin_T<4, 4>(L.Wv, LDW, k, val, lane);    // v = v_fc(k)   (reference quirk, :77)
+      lin<SPL, 4, 4>(L.Wk, LDW, fcur, k, lane);   // k = k_fc(feat)
+      lin<SPL, 4, 4>(L.Wv, LDW, k, val, lane);    // v = v_fc(k)   (reference quirk, :77)
       // pos = pos_fc(ray_diff): 4 -> 8 (ReLU) -> 64
       f4 ph = mfma16(p0w, rd, ld4(L.bP0 + 4 * g));
       ph = f4_relu(ph);
       f4 pos[4];
 #pragma unroll
       for (int M = 0; M < 4; ++M) pos[M] = ld4(L.bP2 + 16 * M + 4 * g);
-      lin_T<1, 4>(L.P2, VA_LD8, &ph, pos, lane);
+      lin<SPL, 1, 4>(L.P2, VA_LD8, &ph, pos, lane);
       // attn = attn_fc(k - q + pos): 64 -> 8 (ReLU) -> 64
       f4 ain[4];
 #pragma unroll
       for (int M = 0; M < 4; ++M) ain[M] = k[M] - qp[M] + pos[M];
       f4 ah = ld4(L.bA0 + 4 * g);
-      lin_T<4, 1>(L.A0, LDW, ain, &ah, lane);
+      lin<SPL, 4, 1>(L.A0, LDW, ain, &ah, lane);
       ah = f4_relu(ah);
       f4 a[4];
 #pragma unroll
       for (int M = 0; M < 4; ++M) a[M] = ld4(L.bA2 + 16 * M + 4 * g);
-      lin_T<1, 4>(L.A2, VA_LD8, &ah, a, lane);
+      lin<SPL, 1, 4>(L.A2, VA_LD8, &ah, a, lane);
       if (mk == 0.0f) {
 #pragma unroll
         for (int M = 0; M < 4; ++M) a[M] = f4_splat(-1e9f);  // masked_fill (:83)
@@ -396,7 +402,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
       xs[M] = acc[M] * rl[M];
       y[M] = ld4(L.bO + 16 * M + 4 * g);
     }
-    lin_T<4, 4>(L.Wo, LDW, xs, y, lane);
+    lin<SPL, 4, 4>(L.Wo, LDW, xs, y, lane);
     if (valid) {
 #pragma unroll
       for (int M = 0; M < 4; ++M) st4(q_out + (size_t)n * C64 + 16 * M + 4 * g, y[M] + xq[M]);
@@ -414,20 +420,23 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
 // ------------------------------------------------------------------------------------ feed-forward
 // LDS: W1 [256][68] | W2 [64][260] | b1 [256] | b2 [64] | gamma [64] | beta [64]
 #define FF_LD2 260
-constexpr int FF_LDS_FLOATS = 256 * LDW + 64 * FF_LD2 + 256 + 64 * 3;
+constexpr int ff_lds_floats(bool spl) {
+  return wimg_floats(spl, 256, 4, LDW) + wimg_floats(spl, 64, 16, FF_LD2) + 256 + 64 * 3;
+}
 
+template <bool SPL>
 __global__ void __launch_bounds__(FF_TPB)
 k_ff(const float* __restrict__ norm_w, const float* __restrict__ norm_b, gpn_linear_t fc1,
      gpn_linear_t fc2, const float* __restrict__ x_in, long long N, float* __restrict__ x_out) {
   float* W1 = smem;
-  float* W2 = W1 + 256 * LDW;
-  float* b1 = W2 + 64 * FF_LD2;
+  float* W2 = W1 + wimg_floats(SPL, 256, 4, LDW);
+  float* b1 = W2 + wimg_floats(SPL, 64, 16, FF_LD2);
   float* b2 = b1 + 256;
   float* gam = b2 + 64;
   float* bet = gam + 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  stage_matrix(W1, LDW, fc1.w, 256, 64, tid, FF_TPB);
-  stage_matrix(W2, FF_LD2, fc2.w, 64, 256, tid, FF_TPB);
+  stage_w<SPL>(W1, LDW, fc1.w, 256, 64, 256, 4, tid, FF_TPB);
+  stage_w<SPL>(W2, FF_LD2, fc2.w, 64, 256, 64, 16, tid, FF_TPB);
   stage_vector(b1, 256, fc1.b, 256, tid, FF_TPB);
   stage_vector(b2, 64, fc2.b, 64, tid, FF_TPB);
   stage_vector(gam, 64, norm_w, 64, tid, FF_TPB);
@@ -446,12 +455,12 @@ k_ff(const float* __restrict__ norm_w, const float* __restrict__ norm_b, gpn_lin
     layernorm_T(x, xn, gam, bet, 1e-6f, lane);
 #pragma unroll
     for (int M = 0; M < 16; ++M) h[M] = ld4(b1 + 16 * M + 4 * g);
-    lin_T<4, 16>(W1, LDW, xn, h, lane);
+    lin<SPL, 4, 16>(W1, LDW, xn, h, lane);
 #pragma unroll
     for (int M = 0; M < 16; ++M) h[M] = f4_relu(h[M]);
 #pragma unroll
     for (int M = 0; M < 4; ++M) y[M] = ld4(b2 + 16 * M + 4 * g);
-    lin_T<16, 4>(W2, FF_LD2, h, y, lane);
+    lin<SPL, 16, 4>(W2, FF_LD2, h, y, lane);
     if (valid) {
 #pragma unroll
       for (int M = 0; M < 4; ++M) st4(x_out + (size_t)n * C64 + 16 * M + 4 * g, y[M] + x[M]);
@@ -462,18 +471,21 @@ k_ff(const float* __restrict__ norm_w, const float* __restrict__ norm_b, gpn_lin
 // ------------------------------------------------------------------------------------ q positional MLP
 // input = [q (64) | emb (126 + 2 zero pad)] = 192 channels; LDS: W0 [64][196] | W2 [64][68] | b0 | b2
 #define QP_LD0 196
-constexpr int QP_LDS_FLOATS = 64 * QP_LD0 + 64 * LDW + 128;
+constexpr int qp_lds_floats(bool spl) {
+  return wimg_floats(spl, 64, 12, QP_LD0) + wimg_floats(spl, 64, 4, LDW) + 128;
+}
 
+template <bool SPL>
 __global__ void __launch_bounds__(QP_TPB)
 k_qpos(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ q_in,
        const float* __restrict__ emb, long long N, float* __restrict__ q_out) {
   float* W0 = smem;
-  float* W2 = W0 + 64 * QP_LD0;
-  float* b0 = W2 + 64 * LDW;
+  float* W2 = W0 + wimg_floats(SPL, 64, 12, QP_LD0);
+  float* b0 = W2 + wimg_floats(SPL, 64, 4, LDW);
   float* b2 = b0 + 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  stage_padded(W0, QP_LD0, 64, 192, fc0.w, 64, 190, tid, QP_TPB);
-  stage_matrix(W2, LDW, fc2.w, 64, 64, tid, QP_TPB);
+  stage_w<SPL>(W0, QP_LD0, fc0.w, 64, 190, 64, 12, tid, QP_TPB);
+  stage_w<SPL>(W2, LDW, fc2.w, 64, 64, 64, 4, tid, QP_TPB);
   stage_vector(b0, 64, fc0.b, 64, tid, QP_TPB);
   stage_vector(b2, 64, fc2.b, 64, tid, QP_TPB);
   __syncthreads();
@@ -491,13 +503,13 @@ k_qpos(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ q_in,
     for (int T = 0; T < 8; ++T) x[4 + T] = ld4(emb + (size_t)nc * GPN_EMB + 16 * T + 4 * g);
 #pragma unroll
     for (int M = 0; M < 4; ++M) h[M] = ld4(b0 + 16 * M + 4 * g);
-    lin_T<12, 4>(W0, QP_LD0, x, h, lane);
+    lin<SPL, 12, 4>(W0, QP_LD0, x, h, lane);
 #pragma unroll
     for (int M = 0; M < 4; ++M) {
       h[M] = f4_relu(h[M]);
       y[M] = ld4(b2 + 16 * M + 4 * g);
     }
-    lin_T<4, 4>(W2, LDW, h, y, lane);
+    lin<SPL, 4, 4>(W2, LDW, h, y, lane);
     if (valid) {
 #pragma unroll
       for (int M = 0; M < 4; ++M) st4(q_out + (size_t)n * C64 + 16 * M + 4 * g, y[M]);
@@ -924,11 +936,16 @@ extern "C" int gpn_rgbfeat(const gpn_linear_t* fc0, const gpn_linear_t* fc2, con
               "gpn_rgbfeat: need 1<=V<=%d, in_ch<=48 (got V=%d in_ch=%d)", GPN_MAX_VIEWS, V, in_ch);
   GPN_REQUIRE(aligned16(feat) && aligned16(q0), "gpn_rgbfeat: outputs must be 16-byte aligned");
   if (N == 0) return GPN_OK;
-  const size_t lds = sizeof(float) * (64 * RF_LD0 + 64 * LDW + 128);
+  const bool spl = gpn_precision() == GPN_PREC_BF16X3;
+  const size_t lds = sizeof(float) * (wimg_floats(spl, 64, 3, RF_LD0) + wimg_floats(spl, 64, 4, LDW) + 128);
   const int grid = persistent_grid(((long long)N + (RF_TPB / 4) - 1) / (RF_TPB / 4));
   GpnStageTimer timer_k_rgbfeat_(GPN_ST_RGBFEAT, (hipStream_t)stream);
-  hipLaunchKernelGGL(k_rgbfeat, dim3(grid), dim3(RF_TPB), lds, (hipStream_t)stream, *fc0, *fc2,
-                     rgb_feat, (long long)N, V, in_ch, feat, q0);
+  if (spl)
+    hipLaunchKernelGGL(k_rgbfeat<true>, dim3(grid), dim3(RF_TPB), lds, (hipStream_t)stream, *fc0, *fc2,
+                       rgb_feat, (long long)N, V, in_ch, feat, q0);
+  else
+    hipLaunchKernelGGL(k_rgbfeat<false>, dim3(grid), dim3(RF_TPB), lds, (hipStream_t)stream, *fc0, *fc2,
+                       rgb_feat, (long long)N, V, in_ch, feat, q0);
   GPN_LAUNCH_CHECK("k_rgbfeat");
   return GPN_OK;
 }
@@ -971,13 +988,19 @@ extern "C" int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const
   GPN_REQUIRE(aligned16(q_in) && aligned16(feat) && aligned16(q_out) && aligned16(logits) &&
                   aligned16(stats), "gpn_view_attn: tensors must be 16-byte aligned");
   if (N == 0) return GPN_OK;
-  const size_t lds = sizeof(float) * VIEW_LDS_FLOATS;
-  int rc = set_lds_limit(reinterpret_cast<const void*>(k_view_attn), lds);
+  const bool spl = gpn_precision() == GPN_PREC_BF16X3;
+  const size_t lds = sizeof(float) * view_lds_floats(spl);
+  int rc = set_lds_limit(spl ? reinterpret_cast<const void*>(k_view_attn<true>)
+                             : reinterpret_cast<const void*>(k_view_attn<false>), lds);
   if (rc) return rc;
   const int grid = persistent_grid(((long long)N + (VA_TPB / 4) - 1) / (VA_TPB / 4));
   GpnStageTimer timer_k_view_attn_(GPN_ST_VIEW_ATTN, (hipStream_t)stream);
-  hipLaunchKernelGGL(k_view_attn, dim3(grid), dim3(VA_TPB), lds, (hipStream_t)stream, *L, q_in, feat,
-                     ray_diff, mask, perm, (long long)N, V, q_out, logits, stats);
+  if (spl)
+    hipLaunchKernelGGL(k_view_attn<true>, dim3(grid), dim3(VA_TPB), lds, (hipStream_t)stream, *L, q_in,
+                       feat, ray_diff, mask, perm, (long long)N, V, q_out, logits, stats);
+  else
+    hipLaunchKernelGGL(k_view_attn<false>, dim3(grid), dim3(VA_TPB), lds, (hipStream_t)stream, *L, q_in,
+                       feat, ray_diff, mask, perm, (long long)N, V, q_out, logits, stats);
   GPN_LAUNCH_CHECK("k_view_attn");
   return GPN_OK;
 }
@@ -992,12 +1015,18 @@ extern "C" int gpn_ff(const float* norm_w, const float* norm_b, const gpn_linear
   GPN_REQUIRE(aligned16(x_in) && aligned16(x_out), "gpn_ff: tensors must be 16-byte aligned");
   GPN_REQUIRE(N >= 0, "gpn_ff: bad N");
   if (N == 0) return GPN_OK;
-  const size_t lds = sizeof(float) * FF_LDS_FLOATS;
-  int rc = set_lds_limit(reinterpret_cast<const void*>(k_ff), lds);
+  const bool spl = gpn_precision() == GPN_PREC_BF16X3;
+  const size_t lds = sizeof(float) * ff_lds_floats(spl);
+  int rc = set_lds_limit(spl ? reinterpret_cast<const void*>(k_ff<true>)
+                             : reinterpret_cast<const void*>(k_ff<false>), lds);
   if (rc) return rc;
   const int grid = persistent_grid(((long long)N + (FF_TPB / 4) - 1) / (FF_TPB / 4));
   GpnStageTimer timer_k_ff_(GPN_ST_FF, (hipStream_t)stream);
-  hipLaunchKernelGGL(k_ff, dim3(grid), dim3(FF_TPB), lds, (hipStream_t)stream, norm_w, norm_b, *fc1,
+  if (spl)
+    hipLaunchKernelGGL(k_ff<true>, dim3(grid), dim3(FF_TPB), lds, (hipStream_t)stream, norm_w, norm_b, *fc1,
+                     *fc2, x_in, (long long)N, x_out);
+  else
+    hipLaunchKernelGGL(k_ff<false>, dim3(grid), dim3(FF_TPB), lds, (hipStream_t)stream, norm_w, norm_b, *fc1,
                      *fc2, x_in, (long long)N, x_out);
   GPN_LAUNCH_CHECK("k_ff");
   return GPN_OK;
@@ -1013,12 +1042,18 @@ extern "C" int gpn_qpos(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const 
               "gpn_qpos: tensors must be 16-byte aligned");
   GPN_REQUIRE(N >= 0, "gpn_qpos: bad N");
   if (N == 0) return GPN_OK;
-  const size_t lds = sizeof(float) * QP_LDS_FLOATS;
-  int rc = set_lds_limit(reinterpret_cast<const void*>(k_qpos), lds);
+  const bool spl = gpn_precision() == GPN_PREC_BF16X3;
+  const size_t lds = sizeof(float) * qp_lds_floats(spl);
+  int rc = set_lds_limit(spl ? reinterpret_cast<const void*>(k_qpos<true>)
+                             : reinterpret_cast<const void*>(k_qpos<false>), lds);
   if (rc) return rc;
   const int grid = persistent_grid(((long long)N + (QP_TPB / 4) - 1) / (QP_TPB / 4));
   GpnStageTimer timer_k_qpos_(GPN_ST_QPOS, (hipStream_t)stream);
-  hipLaunchKernelGGL(k_qpos, dim3(grid), dim3(QP_TPB), lds, (hipStream_t)stream, *fc0, *fc2, q_in, emb,
+  if (spl)
+    hipLaunchKernelGGL(k_qpos<true>, dim3(grid), dim3(QP_TPB), lds, (hipStream_t)stream, *fc0, *fc2, q_in, emb,
+                     (long long)N, q_out);
+  else
+    hipLaunchKernelGGL(k_qpos<false>, dim3(grid), dim3(QP_TPB), lds, (hipStream_t)stream, *fc0, *fc2, q_in, emb,
                      (long long)N, q_out);
   GPN_LAUNCH_CHECK("k_qpos");
   return GPN_OK;

@@ -125,6 +125,9 @@ class GNT(nn.Module):
         self.in_feat_ch = in_feat_ch
         self._wcache = None
         self._ws = None
+        # 'fp32': exact fp32 MFMA.  'bf16x3': split-bf16 MFMA with fp32 accumulation (~6e-6 of the
+        # tensor scale end to end, 5x the matrix rate); see include/gpnerf_hip.h.
+        self.precision = "fp32"
 
     # ------------------------------------------------------------------ weights -> C struct
     def _weights(self):
@@ -188,6 +191,7 @@ class GNT(nn.Module):
         if S < 1 or S > _lib.MAX_SAMPLES:
             raise ValueError("samples per ray must be in [1,%d] (got %d)" % (_lib.MAX_SAMPLES, S))
         W = self._weights()
+        _lib.set_precision(self.precision)
         ws, need = self._workspace(R, S, V, dev)
         out = torch.empty((R, 3 + S), device=dev)
         depth = torch.empty((R,), device=dev) if z_vals is not None else None

@@ -218,6 +218,19 @@ int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat, const flo
                     int R, int S, int V, gpn_sem_args_t* sem, float* out, float* depth,
                     float* sem_feat, void* workspace, size_t workspace_bytes, gpn_stream_t stream);
 
+/* ------------------------------------------------------------------ arithmetic mode of the GNT linear layers
+ * No counterpart in the reference (which is plain fp32).  Process-global, not thread-safe; read at
+ * launch time by gpn_rgbfeat / gpn_view_attn / gpn_ff / gpn_qpos / gpn_ray_attn.
+ *   GPN_PREC_FP32   v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation (default).
+ *   GPN_PREC_BF16X3 every fp32 operand is split into two bf16 pieces (hi + mid) and a product is
+ *                   w_mid*x_hi + w_hi*x_mid + w_hi*x_hi on v_mfma_f32_16x16x32_bf16 with fp32
+ *                   accumulation: ~2^-16 relative error per product, 5.3x the MFMA rate.
+ *                   Softmax, LayerNorm, residuals, the projector and the semantic pass stay fp32. */
+#define GPN_PREC_FP32 0
+#define GPN_PREC_BF16X3 1
+int gpn_set_precision(int mode);
+int gpn_get_precision(void);
+
 /* ------------------------------------------------------------------ measurement hooks
  * No counterpart in the reference: bench.py uses these to time individual kernels with HIP events on
  * the stream they are launched on, inside the timed region.  gpn_timing_begin creates `max_records`

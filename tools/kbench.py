@@ -8,6 +8,8 @@ dev = torch.device("cuda:0")
 args = types.SimpleNamespace(netwidth=64, trans_depth=8, save_feature=False, semantic_model="fpn", num_classes=20)
 net = GNT(args, 32, 63, 63, ret_alpha=True); net.load_state_dict(synth.gnt_state_dict()); net = net.to(dev).eval()
 W = net._weights(); L = _lib.lib(); st = _lib.stream()
+_lib.set_precision(sys.argv[1] if len(sys.argv) > 1 else "fp32")
+print("precision", _lib.get_precision())
 def timeit(fn, reps=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()
@@ -17,7 +19,7 @@ def timeit(fn, reps=20):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps * 1e3
 V = 10
-for N in (128, 2048, 32768, 65536, 131072, 262144):
+for N in (128, 32768, 131072, 262144):
     q = torch.randn(N, 64, device=dev); qo = torch.empty_like(q)
     feat = torch.randn(N, V, 64, device=dev); rd = torch.randn(N, V, 4, device=dev)
     mask = torch.ones(N, V, device=dev); emb = torch.randn(N, 128, device=dev)

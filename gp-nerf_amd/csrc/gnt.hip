@@ -534,7 +534,12 @@ struct RayCfg {
   static_assert(THREADS <= 1024, "too many waves per workgroup");
 };
 
-template <int NT>
+// Split (bf16x3) mode keeps the same LDS budget with 16-byte units [hi(4) | mid(4)]:
+//   Ks: unit (key, head h, g) = channels 16h+4g..+3 of the key       (row stride 17 units)
+//   Vt: unit (channel, key tile kt, g) = keys 16kt+4g..+3 of channel (row stride 4*NT+1 units)
+// so that one unit is the A operand of both MFMAs of a product: against B = [x_hi | x_hi] it yields
+// a_hi*x_hi + a_mid*x_hi, against B = [x_mid | 0] it yields a_hi*x_mid.
+template <int NT, bool SPL>
 __global__ void __launch_bounds__(RayCfg<NT>::THREADS)
 k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
            float* __restrict__ x_out, float* __restrict__ abar, float* __restrict__ weights) {
@@ -542,6 +547,7 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
   // computed on clamped data and never stored.
   using Cfg = RayCfg<NT>;
   constexpr int SP = Cfg::SP, RPW = Cfg::RPW, LDV = Cfg::LDV, NTHR = Cfg::THREADS;
+  constexpr int KU = 17, VU = 4 * NT + 1;  // row strides of the split images, in 16-byte units
   float* Wq = smem;
   float* Wk = Wq + 64 * LDW;
   float* Wv = Wk + 64 * LDW;
@@ -553,10 +559,10 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
   float* Vt = Ks + RPW * SP * LDW;
   float* part = Vt + RPW * 64 * LDV;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  stage_matrix(Wq, LDW, Lw.q.w, 64, 64, tid, NTHR);
-  stage_matrix(Wk, LDW, Lw.k.w, 64, 64, tid, NTHR);
-  stage_matrix(Wv, LDW, Lw.v.w, 64, 64, tid, NTHR);
-  stage_matrix(Wo, LDW, Lw.out.w, 64, 64, tid, NTHR);
+  stage_w<SPL>(Wq, LDW, Lw.q.w, 64, 64, 64, 4, tid, NTHR);
+  stage_w<SPL>(Wk, LDW, Lw.k.w, 64, 64, 64, 4, tid, NTHR);
+  stage_w<SPL>(Wv, LDW, Lw.v.w, 64, 64, 64, 4, tid, NTHR);
+  stage_w<SPL>(Wo, LDW, Lw.out.w, 64, 64, 64, 4, tid, NTHR);
   stage_vector(bO, 64, Lw.out.b, 64, tid, NTHR);
   stage_vector(gam, 64, Lw.attn_norm_w, 64, tid, NTHR);
   stage_vector(bet, 64, Lw.attn_norm_b, 64, tid, NTHR);
@@ -565,6 +571,8 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
   const int slot = wave / NT, t = wave - slot * NT;
   float* Ks_s = Ks + slot * SP * LDW;
   float* Vt_s = Vt + slot * 64 * LDV;
+  bf8* Ku_s = reinterpret_cast<bf8*>(Ks_s);
+  bf8* Vu_s = reinterpret_cast<bf8*>(Vt_s);
   const int sq = 16 * t + j;          // this lane's query / sample index
   const bool qvalid = sq < S;
   const int sqc = qvalid ? sq : S - 1;
@@ -592,24 +600,39 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
     layernorm_T(x, xn, gam, bet, 1e-6f, lane);
 #pragma unroll
     for (int M = 0; M < 4; ++M) qT[M] = f4_zero();
-    lin_T<4, 4>(Wq, LDW, xn, qT, lane);
-    {
-      f4 kT[4];
+    if constexpr (SPL) {
+      XS xs[2] = {split8(xn[0], xn[1]), split8(xn[2], xn[3])};
+      lin_Sx<4, 4>(Wq, xs, qT, lane);
+      f4 kT[4], vN[4];
 #pragma unroll
-      for (int M = 0; M < 4; ++M) kT[M] = f4_zero();
-      lin_T<4, 4>(Wk, LDW, xn, kT, lane);
+      for (int M = 0; M < 4; ++M) kT[M] = f4_zero(), vN[M] = f4_zero();
+      lin_Sx<4, 4>(Wk, xs, kT, lane);
 #pragma unroll
-      for (int M = 0; M < 4; ++M) st4(Ks_s + (16 * t + j) * LDW + 16 * M + 4 * g, kT[M]);
-    }
-    {
-      f4 vT[4];
+      for (int M = 0; M < 4; ++M) Ku_s[(16 * t + j) * KU + 4 * M + g] = split4(kT[M]);
+      // V in normal orientation: lane (j, g) holds V[key 16t + 4g + reg][channel 16M + j]
+      lin_Sx<4, 4, false>(Wv, xs, vN, lane);
 #pragma unroll
-      for (int M = 0; M < 4; ++M) vT[M] = f4_zero();
-      lin_T<4, 4>(Wv, LDW, xn, vT, lane);
+      for (int M = 0; M < 4; ++M) Vu_s[(16 * M + j) * VU + 4 * t + g] = split4(vN[M]);
+    } else {
+      lin_T<4, 4>(Wq, LDW, xn, qT, lane);
+      {
+        f4 kT[4];
 #pragma unroll
-      for (int M = 0; M < 4; ++M)
+        for (int M = 0; M < 4; ++M) kT[M] = f4_zero();
+        lin_T<4, 4>(Wk, LDW, xn, kT, lane);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Vt_s[(16 * M + 4 * g + r) * LDV + 16 * t + j] = vT[M][r];
+        for (int M = 0; M < 4; ++M) st4(Ks_s + (16 * t + j) * LDW + 16 * M + 4 * g, kT[M]);
+      }
+      {
+        f4 vT[4];
+#pragma unroll
+        for (int M = 0; M < 4; ++M) vT[M] = f4_zero();
+        lin_T<4, 4>(Wv, LDW, xn, vT, lane);
+#pragma unroll
+        for (int M = 0; M < 4; ++M)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Vt_s[(16 * M + 4 * g + r) * LDV + 16 * t + j] = vT[M][r];
+      }
     }
     __syncthreads();
 
@@ -619,16 +642,34 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
       // S^T tile: rows = keys, columns (lanes) = this wave's 16 queries; k-dim = the head's 16 channels
-      f4 sT[NT], kf[NT];
+      f4 sT[NT];
+      if constexpr (SPL) {
+        const bf8 qs = split4(qT[h]);
+        bf8 qb1, qb2;
 #pragma unroll
-      for (int kt = 0; kt < NT; ++kt) {
-        sT[kt] = f4_zero();
-        kf[kt] = ld4(Ks_s + (16 * kt + j) * LDW + 16 * h + 4 * g);
+        for (int e = 0; e < 4; ++e) {
+          qb1[e] = qs[e], qb1[4 + e] = qs[e];
+          qb2[e] = qs[4 + e], qb2[4 + e] = (__bf16)0.0f;
+        }
+        bf8 ku[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) ku[kt] = Ku_s[(16 * kt + j) * KU + 4 * h + g];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) sT[kt] = mfma_bf(ku[kt], qb2, f4_zero());
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) sT[kt] = mfma_bf(ku[kt], qb1, sT[kt]);
+      } else {
+        f4 kf[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+          sT[kt] = f4_zero();
+          kf[kt] = ld4(Ks_s + (16 * kt + j) * LDW + 16 * h + 4 * g);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int kt = 0; kt < NT; ++kt) sT[kt] = mfma16(kf[kt][r], qT[h][r], sT[kt]);
       }
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) sT[kt] = mfma16(kf[kt][r], qT[h][r], sT[kt]);
       // softmax over keys (registers x the 4 lane groups), scores / sqrt(16)
       float mx = -INFINITY;
 #pragma unroll
@@ -664,13 +705,29 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
       }
       // O^T[h] = V_h^T . P^T : A = V (channels of head h on rows), B = P^T (keys in registers)
       f4 o0 = f4_zero(), o1 = f4_zero();
+      if constexpr (SPL) {
 #pragma unroll
-      for (int kt = 0; kt < NT; ++kt) {
-        const f4 vf = ld4(Vt_s + (16 * h + j) * LDV + 16 * kt + 4 * g);
+        for (int kt = 0; kt < NT; ++kt) {
+          const bf8 vu = Vu_s[(16 * h + j) * VU + 4 * kt + g];
+          const bf8 ps = split4(sT[kt]);
+          bf8 pb1, pb2;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if ((kt & 1) == 0) o0 = mfma16(vf[r], sT[kt][r], o0);
-          else o1 = mfma16(vf[r], sT[kt][r], o1);
+          for (int e = 0; e < 4; ++e) {
+            pb1[e] = ps[e], pb1[4 + e] = ps[e];
+            pb2[e] = ps[4 + e], pb2[4 + e] = (__bf16)0.0f;
+          }
+          if ((kt & 1) == 0) o0 = mfma_bf(vu, pb1, mfma_bf(vu, pb2, o0));
+          else o1 = mfma_bf(vu, pb1, mfma_bf(vu, pb2, o1));
+        }
+      } else {
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+          const f4 vf = ld4(Vt_s + (16 * h + j) * LDV + 16 * kt + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if ((kt & 1) == 0) o0 = mfma16(vf[r], sT[kt][r], o0);
+            else o1 = mfma16(vf[r], sT[kt][r], o1);
+          }
         }
       }
       oT[h] = o0 + o1;
@@ -678,7 +735,7 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
     f4 y[4];
 #pragma unroll
     for (int M = 0; M < 4; ++M) y[M] = ld4(bO + 16 * M + 4 * g);
-    lin_T<4, 4>(Wo, LDW, oT, y, lane);
+    lin<SPL, 4, 4>(Wo, LDW, oT, y, lane);
     if (valid) {
       if (qvalid) {
         const size_t orow = ((size_t)ray * S + sq) * C64;
@@ -1059,19 +1116,27 @@ extern "C" int gpn_qpos(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const 
   return GPN_OK;
 }
 
-template <int NT>
-static int launch_ray_attn(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,
-                           float* abar, float* weights, hipStream_t stream) {
+template <int NT, bool SPL>
+static int launch_ray_attn_p(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,
+                             float* abar, float* weights, hipStream_t stream) {
   using Cfg = RayCfg<NT>;
   const size_t lds = sizeof(float) * Cfg::LDS_FLOATS;
-  int rc = set_lds_limit(reinterpret_cast<const void*>(k_ray_attn<NT>), lds);
+  int rc = set_lds_limit(reinterpret_cast<const void*>(k_ray_attn<NT, SPL>), lds);
   if (rc) return rc;
   const int grid = persistent_grid(((long long)R + Cfg::RPW - 1) / Cfg::RPW);
   GpnStageTimer timer_k_ray_attn_(GPN_ST_RAY_ATTN, (hipStream_t)stream);
-  hipLaunchKernelGGL(k_ray_attn<NT>, dim3(grid), dim3(Cfg::THREADS), lds, stream, *L, x_in, R, S,
+  hipLaunchKernelGGL((k_ray_attn<NT, SPL>), dim3(grid), dim3(Cfg::THREADS), lds, stream, *L, x_in, R, S,
                      x_out, abar, weights);
   GPN_LAUNCH_CHECK("k_ray_attn");
   return GPN_OK;
+}
+
+template <int NT>
+static int launch_ray_attn(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,
+                           float* abar, float* weights, hipStream_t stream) {
+  if (gpn_precision() == GPN_PREC_BF16X3)
+    return launch_ray_attn_p<NT, true>(L, x_in, R, S, x_out, abar, weights, stream);
+  return launch_ray_attn_p<NT, false>(L, x_in, R, S, x_out, abar, weights, stream);
 }
 
 extern "C" int gpn_ray_attn(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,

@@ -219,14 +219,24 @@ __host__ __device__ constexpr int wimg_floats(bool split, int prow, int kt, int 
   return split ? prow * (((kt + 1) / 2) * 8 + 1) * 4 : prow * ld;
 }
 
-// y[M] += W . x in split mode; same contract as lin_T (x, y are fp32 T-tiles).
-template <int KT, int MT>
-__device__ __forceinline__ void lin_S(const float* Wf, const f4* x, f4* y, int lane) {
+// [hi(a) | mid(a)] of four fp32 values as one 16-byte unit
+__device__ __forceinline__ bf8 split4(f4 a) {
+  bf8 u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    u[i] = (__bf16)a[i];
+    u[4 + i] = (__bf16)(a[i] - (float)u[i]);
+  }
+  return u;
+}
+
+// y[M] += W . x in split mode on pre-split activations xs[(KT+1)/2].  TRANSPOSED = true keeps the
+// T-tile orientation of lin_T (weights are the A operand); false swaps the operands, so the result
+// comes out in normal orientation: lane (j, g) holds Y[point 4g + reg][channel 16M + j].
+template <int KT, int MT, bool TRANSPOSED = true>
+__device__ __forceinline__ void lin_Sx(const float* Wf, const XS* xs, f4* y, int lane) {
   constexpr int KP = (KT + 1) / 2, RS = KP * 8 + 1;
   const bf8* wp = reinterpret_cast<const bf8*>(Wf) + (lane & 15) * RS + (lane >> 4);
-  XS xs[KP];
-#pragma unroll
-  for (int P = 0; P < KP; ++P) xs[P] = split8(x[2 * P], 2 * P + 1 < KT ? x[2 * P + 1] : f4_zero());
   constexpr int MC = MT < 4 ? MT : 4;
   static_assert(MT % MC == 0, "MT must be a multiple of the accumulator chunk");
 #pragma unroll
@@ -248,12 +258,21 @@ __device__ __forceinline__ void lin_S(const float* Wf, const f4* x, f4* y, int l
         }
       }
       // small terms first, so that they are not rounded away against the large one
+      if constexpr (TRANSPOSED) {
 #pragma unroll
-      for (int m = 0; m < MC; ++m) y[M0 + m] = mfma_bf(wm[m], xs[P].hi, y[M0 + m]);
+        for (int m = 0; m < MC; ++m) y[M0 + m] = mfma_bf(wm[m], xs[P].hi, y[M0 + m]);
 #pragma unroll
-      for (int m = 0; m < MC; ++m) y[M0 + m] = mfma_bf(wh[m], xs[P].mid, y[M0 + m]);
+        for (int m = 0; m < MC; ++m) y[M0 + m] = mfma_bf(wh[m], xs[P].mid, y[M0 + m]);
 #pragma unroll
-      for (int m = 0; m < MC; ++m) y[M0 + m] = mfma_bf(wh[m], xs[P].hi, y[M0 + m]);
+        for (int m = 0; m < MC; ++m) y[M0 + m] = mfma_bf(wh[m], xs[P].hi, y[M0 + m]);
+      } else {
+#pragma unroll
+        for (int m = 0; m < MC; ++m) y[M0 + m] = mfma_bf(xs[P].hi, wm[m], y[M0 + m]);
+#pragma unroll
+        for (int m = 0; m < MC; ++m) y[M0 + m] = mfma_bf(xs[P].mid, wh[m], y[M0 + m]);
+#pragma unroll
+        for (int m = 0; m < MC; ++m) y[M0 + m] = mfma_bf(xs[P].hi, wh[m], y[M0 + m]);
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (P + 1 < KP) {
 #pragma unroll
@@ -261,6 +280,16 @@ __device__ __forceinline__ void lin_S(const float* Wf, const f4* x, f4* y, int l
       }
     }
   }
+}
+
+// y[M] += W . x in split mode; same contract as lin_T (x, y are fp32 T-tiles).
+template <int KT, int MT>
+__device__ __forceinline__ void lin_S(const float* Wf, const f4* x, f4* y, int lane) {
+  constexpr int KP = (KT + 1) / 2;
+  XS xs[KP];
+#pragma unroll
+  for (int P = 0; P < KP; ++P) xs[P] = split8(x[2 * P], 2 * P + 1 < KT ? x[2 * P + 1] : f4_zero());
+  lin_Sx<KT, MT>(Wf, xs, y, lane);
 }
 
 template <bool SP, int KT, int MT>

@@ -67,13 +67,14 @@ class ProjectArgs(C.Structure):
 
 class SemArgs(C.Structure):
     _fields_ = [("R", C.c_int), ("S", C.c_int), ("V", C.c_int), ("depth", C.c_int),
-                ("logits", C.c_void_p * MAX_DEPTH), ("stats", C.c_void_p * MAX_DEPTH),
-                ("abar", C.c_void_p * MAX_DEPTH), ("mask", C.c_void_p),
+                ("logits", C.c_void_p), ("stats", C.c_void_p), ("abar", C.c_void_p),
+                ("mask", C.c_void_p),
                 ("deep_dense", C.c_void_p),
                 ("deep_map", C.c_void_p), ("deep_h", C.c_int), ("deep_w", C.c_int),
                 ("xyz", C.c_void_p), ("proj", C.c_void_p),
                 ("img_h", C.c_float), ("img_w", C.c_float),
-                ("sem3d", C.c_void_p), ("pre", C.c_void_p)]
+                ("sem3d", C.c_void_p), ("pre", C.c_void_p),
+                ("ray_w", C.c_int), ("ray_c0", C.c_int)]
 
 
 _P = C.c_void_p
@@ -92,12 +93,12 @@ _SIGS = {
     "gpn_rgbfeat": (C.c_int, [C.POINTER(Linear), C.POINTER(Linear), _P, C.c_int, C.c_int, C.c_int,
                               _P, _P, _P]),
     "gpn_view_attn": (C.c_int, [C.POINTER(ViewLayer), _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P,
-                                _P, _P]),
+                                C.c_int, _P, C.c_int, _P]),
     "gpn_vis_order_scratch_bytes": (C.c_size_t, []),
     "gpn_vis_order": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P]),
     "gpn_ff": (C.c_int, [_P, _P, C.POINTER(Linear), C.POINTER(Linear), _P, C.c_int, _P, _P]),
     "gpn_qpos": (C.c_int, [C.POINTER(Linear), C.POINTER(Linear), _P, _P, C.c_int, _P, _P]),
-    "gpn_ray_attn": (C.c_int, [C.POINTER(RayLayer), _P, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "gpn_ray_attn": (C.c_int, [C.POINTER(RayLayer), _P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P]),
     "gpn_sem_aggregate": (C.c_int, [C.POINTER(SemArgs), _P]),
     "gpn_heads": (C.c_int, [C.POINTER(GntWeights), _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P,
                             _P]),

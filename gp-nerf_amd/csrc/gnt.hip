@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(VA_TPB)
 k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __restrict__ feat,
             const float* __restrict__ ray_diff, const float* __restrict__ mask,
             const int* __restrict__ perm, long long N, int V, float* __restrict__ q_out,
-            float* __restrict__ logits, float* __restrict__ stats) {
+            float* __restrict__ logits, int logits_ld, float* __restrict__ stats, int stats_ld) {
   const ViewLds L = view_lds<SPL>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   stage_w<SPL>(L.Wq, LDW, Lw.q.w, 64, 64, 64, 4, tid, VA_TPB);
@@ -375,7 +375,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
         for (int M = 0; M < 4; ++M) a[M] = f4_splat(-1e9f);  // masked_fill (:83)
       }
       if (logits != nullptr && valid && mk != 0.0f) {  // masked pairs are never read back
-        float* lo = logits + ((size_t)n * V + v) * C64 + 4 * g;
+        float* lo = logits + ((size_t)n * V + v) * logits_ld + 4 * g;
 #pragma unroll
         for (int M = 0; M < 4; ++M) st4(lo + 16 * M, a[M]);
       }
@@ -409,8 +409,8 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
       if (stats != nullptr) {
 #pragma unroll
         for (int M = 0; M < 4; ++M) {
-          st4(stats + (size_t)n * 128 + 16 * M + 4 * g, mrun[M]);
-          st4(stats + (size_t)n * 128 + 64 + 16 * M + 4 * g, rl[M]);
+          st4(stats + (size_t)n * stats_ld + 16 * M + 4 * g, mrun[M]);
+          st4(stats + (size_t)n * stats_ld + 64 + 16 * M + 4 * g, rl[M]);
         }
       }
     }
@@ -542,7 +542,8 @@ struct RayCfg {
 template <int NT, bool SPL>
 __global__ void __launch_bounds__(RayCfg<NT>::THREADS)
 k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
-           float* __restrict__ x_out, float* __restrict__ abar, float* __restrict__ weights) {
+           float* __restrict__ x_out, float* __restrict__ abar, int abar_ld,
+           float* __restrict__ weights) {
   // S (<= SP) real samples per ray; keys >= S are masked out of the softmax, queries >= S are
   // computed on clamped data and never stored.
   using Cfg = RayCfg<NT>;
@@ -761,7 +762,7 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
         float c = 0.f;
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) c += part[(sl * NT + tt) * 4 * SP + rem];
-        if (rr < R && key < S) abar[((size_t)rr * 4 + h) * S + key] = c / (float)S;
+        if (rr < R && key < S) abar[((size_t)rr * S + key) * abar_ld + h] = c / (float)S;
       }
     }
     // no third barrier: the next iteration writes Ks / Vt only (every wave is past the attention
@@ -778,10 +779,13 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
 // into W3d / W2d and applied to the sampled (or dense) deep-semantic row.  Masked views have weight
 // exactly 0 and are skipped; a sample with no visible view has the uniform weight 1/V in every layer.
 #define SEM_RAYS 8
-__global__ void __launch_bounds__(SEM_RAYS * 64, 4)
+template <int DEPTH>
+__global__ void __launch_bounds__(SEM_RAYS * 64, 4)  // 4 waves per SIMD: two workgroups per CU
 k_sem(gpn_sem_args_t a) {
   __shared__ float sP[GPN_MAX_VIEWS * 12];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // the wave index (hence the ray and every per-sample address) is wave-uniform: keep it in SGPRs
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2): give each XCD a
   // contiguous run of ray groups.
   int blk = blockIdx.x;
@@ -794,80 +798,102 @@ k_sem(gpn_sem_args_t a) {
     for (int i = tid; i < V * 12; i += SEM_RAYS * 64) sP[i] = a.proj[(i / 12) * 16 + (i % 12)];
   }
   __syncthreads();
-  const int r = blk * SEM_RAYS + wave;
-  const bool rvalid = r < a.R;
-  const int rc = rvalid ? r : a.R - 1;
+  // ray of this wave: 8 consecutive rays, or (with the row hint) 8 consecutive pixels of one image
+  // row, the workgroups of an XCD covering a band of columns over all rows of the chunk
+  int r = blk * SEM_RAYS + wave;
+  bool rvalid = r < a.R;
+  if (a.ray_w > 0) {
+    const int rows = (a.ray_c0 + a.R + a.ray_w - 1) / a.ray_w;
+    const int cg = blk / rows, row = blk - cg * rows, col = cg * SEM_RAYS + wave;
+    r = row * a.ray_w + col - a.ray_c0;
+    rvalid = col < a.ray_w && r >= 0 && r < a.R;
+  }
+  if (!__syncthreads_or(rvalid)) return;  // padding group of the banded layout
+  const int rc = __builtin_amdgcn_readfirstlane(rvalid ? r : (r < 0 ? 0 : a.R - 1));
   const int c8 = lane * 8, head = lane >> 4;  // lane == channel group
   f4 acc2a = f4_zero(), acc2b = f4_zero();
   const size_t rs = (size_t)a.deep_w * GPN_SEM;
   const float inv_v = 1.0f / (float)V;
+  const unsigned all_views = V >= 32 ? 0xffffffffu : ((1u << V) - 1u);
+  const bool dense = a.deep_dense != nullptr;
+  // visibility bits: lane v reads the mask of view v, one sample ahead
+  float mv_next = lane < V ? a.mask[(size_t)rc * S * V + lane] : 0.0f;
   for (int s = 0; s < S; ++s) {
     const size_t n = (size_t)rc * S + s;
-    unsigned vis = 0;
-    for (int v = 0; v < V; ++v) vis |= (a.mask[n * V + v] != 0.0f ? 1u : 0u) << v;
-    float mx[GPN_MAX_DEPTH], rl[GPN_MAX_DEPTH], ab[GPN_MAX_DEPTH];
+    // per-sample state, every load issued before the first use: softmax stats and mean ray
+    // attention of every layer, the sample position, the next sample's mask
+    const float mv = mv_next;
+    if (s + 1 < S) mv_next = lane < V ? a.mask[(n + 1) * V + lane] : 0.0f;
+    float mx[DEPTH], rl[DEPTH], ab[DEPTH];
+    const float* abp = a.abar + n * (DEPTH * 4);
+    const float* stp = a.stats + n * (DEPTH * 128);
+#pragma unroll
+    for (int l = 0; l < DEPTH; ++l) {
+      ab[l] = abp[4 * l + head];
+      mx[l] = __builtin_nontemporal_load(stp + (128 * l + lane));
+      rl[l] = __builtin_nontemporal_load(stp + (128 * l + 64 + lane));
+    }
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (!dense) px = a.xyz[n * 3 + 0], py = a.xyz[n * 3 + 1], pz = a.xyz[n * 3 + 2];
+    const unsigned vis = (unsigned)__ballot(mv != 0.0f);
     float w3u = 0.f, w2u = 0.f;  // uniform weights of an all-masked sample
 #pragma unroll
-    for (int l = 0; l < GPN_MAX_DEPTH; ++l) {
-      mx[l] = rl[l] = ab[l] = 0.f;
-      if (l < a.depth) {
-        ab[l] = a.abar[l][((size_t)rc * 4 + head) * S + s];
-        if (vis != 0) {
-          mx[l] = a.stats[l][n * 128 + lane];
-          rl[l] = a.stats[l][n * 128 + 64 + lane];
-        }
-        w3u += inv_v;
-        w2u += ab[l] * inv_v;
-      }
-    }
+    for (int l = 0; l < DEPTH; ++l) w3u += inv_v, w2u += ab[l] * inv_v;
     f4 acc3a = f4_zero(), acc3b = f4_zero();
-    float px = 0.f, py = 0.f, pz = 0.f;
-    if (a.deep_map != nullptr) px = a.xyz[n * 3 + 0], py = a.xyz[n * 3 + 1], pz = a.xyz[n * 3 + 2];
-    unsigned live = vis != 0 ? vis : (V >= 32 ? 0xffffffffu : ((1u << V) - 1u));
+    unsigned live = vis != 0 ? vis : all_views;
     while (live) {
       const int v = __builtin_ctz(live);
       live &= live - 1;
-      f4 tnw[2], tne[2], tsw[2], tse[2];
-      GpnTaps t;
-      if (a.deep_dense != nullptr) {
-        tnw[0] = ld4(a.deep_dense + (n * V + v) * GPN_SEM + c8);
-        tnw[1] = ld4(a.deep_dense + (n * V + v) * GPN_SEM + c8 + 4);
+      float lg[DEPTH];
+      if (vis != 0) {
+        const float* lgp = a.logits + (n * V + v) * (DEPTH * C64);
+#pragma unroll
+        for (int l = 0; l < DEPTH; ++l) lg[l] = __builtin_nontemporal_load(lgp + (C64 * l + lane));
+      }
+      f4 d0, d1;
+      if (dense) {
+        const float* dd = a.deep_dense + (n * V + v) * GPN_SEM;
+        d0 = ld4(dd + (unsigned)c8);
+        d1 = ld4(dd + (unsigned)(c8 + 4));
       } else {
         const GpnPix pp = gpn_project(sP + v * 12, px, py, pz);
-        t = gpn_taps(pp.px, pp.py, a.img_h, a.img_w, a.deep_h, a.deep_w);
-        const float* dm = a.deep_map + (size_t)v * a.deep_h * rs + c8;
-        const size_t o00 = (size_t)t.y0 * rs + (size_t)t.x0 * GPN_SEM;
+        const GpnTaps t = gpn_taps(pp.px, pp.py, a.img_h, a.img_w, a.deep_h, a.deep_w);
+        // all four taps are loaded from clamped (always valid) addresses; out-of-map taps are
+        // zeroed afterwards, as grid_sample's zero padding does
+        const int x0 = min(max(t.x0, 0), a.deep_w - 1), x1 = min(max(t.x0 + 1, 0), a.deep_w - 1);
+        const int y0 = min(max(t.y0, 0), a.deep_h - 1), y1 = min(max(t.y0 + 1, 0), a.deep_h - 1);
+        // uniform base of the view's map + 32-bit element offsets (one map is < 2^31 floats)
+        const float* dm = a.deep_map + (size_t)v * a.deep_h * rs;
+        const unsigned urs = (unsigned)rs;
+        const float* p00 = dm + ((unsigned)y0 * urs + (unsigned)x0 * GPN_SEM + (unsigned)c8);
+        const float* p01 = dm + ((unsigned)y0 * urs + (unsigned)x1 * GPN_SEM + (unsigned)c8);
+        const float* p10 = dm + ((unsigned)y1 * urs + (unsigned)x0 * GPN_SEM + (unsigned)c8);
+        const float* p11 = dm + ((unsigned)y1 * urs + (unsigned)x1 * GPN_SEM + (unsigned)c8);
+        f4 tnw[2] = {ld4(p00), ld4(p00 + 4)}, tne[2] = {ld4(p01), ld4(p01 + 4)};
+        f4 tsw[2] = {ld4(p10), ld4(p10 + 4)}, tse[2] = {ld4(p11), ld4(p11 + 4)};
+        const float znw = (t.vy0 && t.vx0) ? 1.0f : 0.0f, zne = (t.vy0 && t.vx1) ? 1.0f : 0.0f;
+        const float zsw = (t.vy1 && t.vx0) ? 1.0f : 0.0f, zse = (t.vy1 && t.vx1) ? 1.0f : 0.0f;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          tnw[h] = tne[h] = tsw[h] = tse[h] = f4_zero();
-          if (t.vy0 && t.vx0) tnw[h] = ld4(dm + o00 + 4 * h);
-          if (t.vy0 && t.vx1) tne[h] = ld4(dm + o00 + GPN_SEM + 4 * h);
-          if (t.vy1 && t.vx0) tsw[h] = ld4(dm + o00 + rs + 4 * h);
-          if (t.vy1 && t.vx1) tse[h] = ld4(dm + o00 + rs + GPN_SEM + 4 * h);
+          if (znw == 0.0f) tnw[h] = f4_zero();
+          if (zne == 0.0f) tne[h] = f4_zero();
+          if (zsw == 0.0f) tsw[h] = f4_zero();
+          if (zse == 0.0f) tse[h] = f4_zero();
         }
-      }
-      float w3 = w3u, w2 = w2u;
-      if (vis != 0) {
-        float lg[GPN_MAX_DEPTH];
-#pragma unroll
-        for (int l = 0; l < GPN_MAX_DEPTH; ++l)
-          lg[l] = l < a.depth ? a.logits[l][(n * V + v) * C64 + lane] : 0.f;
-        w3 = 0.f, w2 = 0.f;
-#pragma unroll
-        for (int l = 0; l < GPN_MAX_DEPTH; ++l) {
-          if (l < a.depth) {
-            const float at = __expf(lg[l] - mx[l]) * rl[l];
-            w3 += at;
-            w2 += ab[l] * at;
-          }
-        }
-      }
-      f4 d0 = tnw[0], d1 = tnw[1];
-      if (a.deep_dense == nullptr) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           d0[c] = gpn_bilerp(tnw[0][c], tne[0][c], tsw[0][c], tse[0][c], t);
           d1[c] = gpn_bilerp(tnw[1][c], tne[1][c], tsw[1][c], tse[1][c], t);
+        }
+      }
+      float w3 = w3u, w2 = w2u;
+      if (vis != 0) {
+        w3 = 0.f, w2 = 0.f;
+#pragma unroll
+        for (int l = 0; l < DEPTH; ++l) {
+          const float at = __expf(lg[l] - mx[l]) * rl[l];
+          w3 += at;
+          w2 += ab[l] * at;
         }
       }
       acc3a = acc3a + d0 * f4_splat(w3);
@@ -876,8 +902,8 @@ k_sem(gpn_sem_args_t a) {
       acc2b = acc2b + d1 * f4_splat(w2);
     }
     if (a.sem3d != nullptr && rvalid) {
-      st4(a.sem3d + n * GPN_SEM + c8, acc3a);
-      st4(a.sem3d + n * GPN_SEM + c8 + 4, acc3b);
+      __builtin_nontemporal_store(acc3a, reinterpret_cast<f4*>(a.sem3d + n * GPN_SEM + c8));
+      __builtin_nontemporal_store(acc3b, reinterpret_cast<f4*>(a.sem3d + n * GPN_SEM + c8 + 4));
     }
     __syncthreads();  // keep the 8 rays of the group on the same sample (cache locality only)
   }
@@ -1030,8 +1056,8 @@ extern "C" int gpn_vis_order(const float* mask, int N, int V, int32_t* perm, voi
 
 extern "C" int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const float* feat,
                              const float* ray_diff, const float* mask, const int32_t* perm, int N,
-                             int V, float* q_out, float* logits, float* stats,
-                             gpn_stream_t stream) {
+                             int V, float* q_out, float* logits, int logits_ld, float* stats,
+                             int stats_ld, gpn_stream_t stream) {
   if (N == 0) return GPN_OK;  // empty batch (pointers may be null)
   GPN_REQUIRE(L && q_in && feat && ray_diff && mask && q_out, "gpn_view_attn: null pointer");
   REQ_LIN(L->q, "gpn_view_attn.q");
@@ -1044,7 +1070,10 @@ extern "C" int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const
               GPN_MAX_VIEWS, V);
   GPN_REQUIRE(aligned16(q_in) && aligned16(feat) && aligned16(q_out) && aligned16(logits) &&
                   aligned16(stats), "gpn_view_attn: tensors must be 16-byte aligned");
-  if (N == 0) return GPN_OK;
+  GPN_REQUIRE(!logits || (logits_ld >= C64 && logits_ld % 4 == 0),
+              "gpn_view_attn: logits_ld must be a multiple of 4 and >= %d (got %d)", C64, logits_ld);
+  GPN_REQUIRE(!stats || (stats_ld >= 2 * C64 && stats_ld % 4 == 0),
+              "gpn_view_attn: stats_ld must be a multiple of 4 and >= %d (got %d)", 2 * C64, stats_ld);
   const bool spl = gpn_precision() == GPN_PREC_BF16X3;
   const size_t lds = sizeof(float) * view_lds_floats(spl);
   int rc = set_lds_limit(spl ? reinterpret_cast<const void*>(k_view_attn<true>)
@@ -1054,10 +1083,12 @@ extern "C" int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const
   GpnStageTimer timer_k_view_attn_(GPN_ST_VIEW_ATTN, (hipStream_t)stream);
   if (spl)
     hipLaunchKernelGGL(k_view_attn<true>, dim3(grid), dim3(VA_TPB), lds, (hipStream_t)stream, *L, q_in,
-                       feat, ray_diff, mask, perm, (long long)N, V, q_out, logits, stats);
+                       feat, ray_diff, mask, perm, (long long)N, V, q_out, logits, logits_ld, stats,
+                       stats_ld);
   else
     hipLaunchKernelGGL(k_view_attn<false>, dim3(grid), dim3(VA_TPB), lds, (hipStream_t)stream, *L, q_in,
-                       feat, ray_diff, mask, perm, (long long)N, V, q_out, logits, stats);
+                       feat, ray_diff, mask, perm, (long long)N, V, q_out, logits, logits_ld, stats,
+                       stats_ld);
   GPN_LAUNCH_CHECK("k_view_attn");
   return GPN_OK;
 }
@@ -1118,7 +1149,7 @@ extern "C" int gpn_qpos(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const 
 
 template <int NT, bool SPL>
 static int launch_ray_attn_p(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,
-                             float* abar, float* weights, hipStream_t stream) {
+                             float* abar, int abar_ld, float* weights, hipStream_t stream) {
   using Cfg = RayCfg<NT>;
   const size_t lds = sizeof(float) * Cfg::LDS_FLOATS;
   int rc = set_lds_limit(reinterpret_cast<const void*>(k_ray_attn<NT, SPL>), lds);
@@ -1126,21 +1157,21 @@ static int launch_ray_attn_p(const gpn_ray_layer_t* L, const float* x_in, int R,
   const int grid = persistent_grid(((long long)R + Cfg::RPW - 1) / Cfg::RPW);
   GpnStageTimer timer_k_ray_attn_(GPN_ST_RAY_ATTN, (hipStream_t)stream);
   hipLaunchKernelGGL((k_ray_attn<NT, SPL>), dim3(grid), dim3(Cfg::THREADS), lds, stream, *L, x_in, R, S,
-                     x_out, abar, weights);
+                     x_out, abar, abar_ld, weights);
   GPN_LAUNCH_CHECK("k_ray_attn");
   return GPN_OK;
 }
 
 template <int NT>
 static int launch_ray_attn(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,
-                           float* abar, float* weights, hipStream_t stream) {
+                           float* abar, int abar_ld, float* weights, hipStream_t stream) {
   if (gpn_precision() == GPN_PREC_BF16X3)
-    return launch_ray_attn_p<NT, true>(L, x_in, R, S, x_out, abar, weights, stream);
-  return launch_ray_attn_p<NT, false>(L, x_in, R, S, x_out, abar, weights, stream);
+    return launch_ray_attn_p<NT, true>(L, x_in, R, S, x_out, abar, abar_ld, weights, stream);
+  return launch_ray_attn_p<NT, false>(L, x_in, R, S, x_out, abar, abar_ld, weights, stream);
 }
 
 extern "C" int gpn_ray_attn(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,
-                            float* abar, float* weights, gpn_stream_t stream) {
+                            float* abar, int abar_ld, float* weights, gpn_stream_t stream) {
   if (R == 0) return GPN_OK;  // empty batch (pointers may be null)
   GPN_REQUIRE(L && x_in && x_out, "gpn_ray_attn: null pointer");
   REQ_LIN(L->q, "gpn_ray_attn.q");
@@ -1151,17 +1182,18 @@ extern "C" int gpn_ray_attn(const gpn_ray_layer_t* L, const float* x_in, int R, 
   GPN_REQUIRE(R >= 0 && S >= 1 && S <= GPN_MAX_SAMPLES,
               "gpn_ray_attn: samples per ray must be in [1,%d] (got %d)", GPN_MAX_SAMPLES, S);
   GPN_REQUIRE(aligned16(x_in) && aligned16(x_out), "gpn_ray_attn: tensors must be 16-byte aligned");
+  GPN_REQUIRE(!abar || abar_ld >= 4, "gpn_ray_attn: abar_ld must be >= 4 (got %d)", abar_ld);
   if (R == 0) return GPN_OK;
   hipStream_t st = (hipStream_t)stream;
   switch ((S + 15) / 16) {
-    case 1: return launch_ray_attn<1>(L, x_in, R, S, x_out, abar, weights, st);
-    case 2: return launch_ray_attn<2>(L, x_in, R, S, x_out, abar, weights, st);
-    case 3: return launch_ray_attn<3>(L, x_in, R, S, x_out, abar, weights, st);
-    case 4: return launch_ray_attn<4>(L, x_in, R, S, x_out, abar, weights, st);
-    case 5: return launch_ray_attn<5>(L, x_in, R, S, x_out, abar, weights, st);
-    case 6: return launch_ray_attn<6>(L, x_in, R, S, x_out, abar, weights, st);
-    case 7: return launch_ray_attn<7>(L, x_in, R, S, x_out, abar, weights, st);
-    default: return launch_ray_attn<8>(L, x_in, R, S, x_out, abar, weights, st);
+    case 1: return launch_ray_attn<1>(L, x_in, R, S, x_out, abar, abar_ld, weights, st);
+    case 2: return launch_ray_attn<2>(L, x_in, R, S, x_out, abar, abar_ld, weights, st);
+    case 3: return launch_ray_attn<3>(L, x_in, R, S, x_out, abar, abar_ld, weights, st);
+    case 4: return launch_ray_attn<4>(L, x_in, R, S, x_out, abar, abar_ld, weights, st);
+    case 5: return launch_ray_attn<5>(L, x_in, R, S, x_out, abar, abar_ld, weights, st);
+    case 6: return launch_ray_attn<6>(L, x_in, R, S, x_out, abar, abar_ld, weights, st);
+    case 7: return launch_ray_attn<7>(L, x_in, R, S, x_out, abar, abar_ld, weights, st);
+    default: return launch_ray_attn<8>(L, x_in, R, S, x_out, abar, abar_ld, weights, st);
   }
 }
 
@@ -1171,8 +1203,7 @@ extern "C" int gpn_sem_aggregate(const gpn_sem_args_t* a, gpn_stream_t stream) {
   GPN_REQUIRE(a->R >= 0 && a->S >= 1 && a->V >= 1 && a->V <= GPN_MAX_VIEWS && a->depth >= 1 &&
                   a->depth <= GPN_MAX_DEPTH, "gpn_sem_aggregate: bad shape");
   GPN_REQUIRE(a->mask && a->pre, "gpn_sem_aggregate: null pointer");
-  for (int l = 0; l < a->depth; ++l)
-    GPN_REQUIRE(a->logits[l] && a->stats[l] && a->abar[l], "gpn_sem_aggregate: null layer %d", l);
+  GPN_REQUIRE(a->logits && a->stats && a->abar, "gpn_sem_aggregate: null logits / stats / abar");
   GPN_REQUIRE((a->deep_dense != nullptr) != (a->deep_map != nullptr),
               "gpn_sem_aggregate: exactly one of deep_dense / deep_map must be given");
   if (a->deep_map) {
@@ -1185,8 +1216,24 @@ extern "C" int gpn_sem_aggregate(const gpn_sem_args_t* a, gpn_stream_t stream) {
   GPN_REQUIRE(aligned16(a->pre) && aligned16(a->sem3d), "gpn_sem_aggregate: outputs must be aligned");
   if (a->R == 0) return GPN_OK;
   GpnStageTimer timer_k_sem_(GPN_ST_SEM, (hipStream_t)stream);
-  hipLaunchKernelGGL(k_sem, dim3(gpn_ceil_div(a->R, SEM_RAYS)), dim3(SEM_RAYS * 64), 0,
-                     (hipStream_t)stream, *a);
+  int groups = gpn_ceil_div(a->R, SEM_RAYS);
+  if (a->ray_w > 0) {
+    GPN_REQUIRE(a->ray_c0 >= 0 && a->ray_c0 < a->ray_w, "gpn_sem_aggregate: ray_c0 must be in [0, ray_w)");
+    const long long rows = ((long long)a->ray_c0 + a->R + a->ray_w - 1) / a->ray_w;
+    groups = (int)(rows * gpn_ceil_div(a->ray_w, SEM_RAYS));
+  }
+  const dim3 grid(groups), block(SEM_RAYS * 64);
+  hipStream_t st = (hipStream_t)stream;
+  switch (a->depth) {
+    case 1: hipLaunchKernelGGL(k_sem<1>, grid, block, 0, st, *a); break;
+    case 2: hipLaunchKernelGGL(k_sem<2>, grid, block, 0, st, *a); break;
+    case 3: hipLaunchKernelGGL(k_sem<3>, grid, block, 0, st, *a); break;
+    case 4: hipLaunchKernelGGL(k_sem<4>, grid, block, 0, st, *a); break;
+    case 5: hipLaunchKernelGGL(k_sem<5>, grid, block, 0, st, *a); break;
+    case 6: hipLaunchKernelGGL(k_sem<6>, grid, block, 0, st, *a); break;
+    case 7: hipLaunchKernelGGL(k_sem<7>, grid, block, 0, st, *a); break;
+    default: hipLaunchKernelGGL(k_sem<8>, grid, block, 0, st, *a); break;
+  }
   GPN_LAUNCH_CHECK("k_sem");
   return GPN_OK;
 }
@@ -1230,9 +1277,9 @@ static GntWs gnt_ws_layout(int R, int S, int V, int depth) {
   w.emb = o, o += align_up(N * GPN_EMB * f);
   w.feat = o, o += align_up(N * V * C64 * f);
   w.q = o, o += align_up(N * C64 * f);
-  w.logits = o, o += depth * align_up(N * V * C64 * f);
-  w.stats = o, o += depth * align_up(N * 128 * f);
-  w.abar = o, o += depth * align_up((size_t)R * 4 * S * f);
+  w.logits = o, o += align_up(N * V * depth * C64 * f);  // [N,V,depth,64]
+  w.stats = o, o += align_up(N * depth * 128 * f);        // [N,depth,128]
+  w.abar = o, o += align_up(N * depth * 4 * f);           // [R,S,depth,4]
   w.weights = o, o += align_up(N * f);
   w.pre = o, o += align_up((size_t)R * GPN_SEM * f);
   w.perm = o, o += align_up(N * sizeof(int));
@@ -1266,7 +1313,7 @@ extern "C" int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat
   if (sem) GPN_REQUIRE(sem_feat, "gpn_gnt_forward: sem given without sem_feat output");
   if (R == 0) return GPN_OK;
   char* ws = static_cast<char*>(workspace);
-  const size_t N = (size_t)R * S, f = sizeof(float);
+  const size_t N = (size_t)R * S;
   float* emb = reinterpret_cast<float*>(ws + L.emb);
   float* feat = reinterpret_cast<float*>(ws + L.feat);
   float* q = reinterpret_cast<float*>(ws + L.q);
@@ -1280,21 +1327,26 @@ extern "C" int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat
                         stream)))
     return rc;
   for (int l = 0; l < D; ++l) {
-    float* lg = sem ? reinterpret_cast<float*>(ws + L.logits + l * align_up(N * V * C64 * f)) : nullptr;
-    float* st = sem ? reinterpret_cast<float*>(ws + L.stats + l * align_up(N * 128 * f)) : nullptr;
-    float* ab = sem ? reinterpret_cast<float*>(ws + L.abar + l * align_up((size_t)R * 4 * S * f)) : nullptr;
+    // side outputs for the semantic aggregation, interleaved over the layers
+    float* lg = sem ? reinterpret_cast<float*>(ws + L.logits) + l * C64 : nullptr;
+    float* st = sem ? reinterpret_cast<float*>(ws + L.stats) + l * 128 : nullptr;
+    float* ab = sem ? reinterpret_cast<float*>(ws + L.abar) + l * 4 : nullptr;
     const gpn_view_layer_t* vl = &W->view[l];
     const gpn_ray_layer_t* rl = &W->ray[l];
-    if ((rc = gpn_view_attn(vl, q, feat, ray_diff, mask, perm, (int)N, V, q, lg, st, stream))) return rc;
+    if ((rc = gpn_view_attn(vl, q, feat, ray_diff, mask, perm, (int)N, V, q, lg, D * C64, st, D * 128,
+                            stream)))
+      return rc;
     if ((rc = gpn_ff(vl->ff_norm_w, vl->ff_norm_b, &vl->ff1, &vl->ff2, q, (int)N, q, stream))) return rc;
     if (l % 2 == 0)
       if ((rc = gpn_qpos(&W->qfc0[l], &W->qfc2[l], q, emb, (int)N, q, stream))) return rc;
-    if ((rc = gpn_ray_attn(rl, q, R, S, q, ab, l == D - 1 ? wts : nullptr, stream))) return rc;
+    if ((rc = gpn_ray_attn(rl, q, R, S, q, ab, D * 4, l == D - 1 ? wts : nullptr, stream))) return rc;
     if ((rc = gpn_ff(rl->ff_norm_w, rl->ff_norm_b, &rl->ff1, &rl->ff2, q, (int)N, q, stream))) return rc;
-    if (sem) sem->logits[l] = lg, sem->stats[l] = st, sem->abar[l] = ab;
   }
   if (sem) {
     sem->R = R, sem->S = S, sem->V = V, sem->depth = D;
+    sem->logits = reinterpret_cast<float*>(ws + L.logits);
+    sem->stats = reinterpret_cast<float*>(ws + L.stats);
+    sem->abar = reinterpret_cast<float*>(ws + L.abar);
     sem->mask = mask;
     sem->pre = pre;
     if ((rc = gpn_sem_aggregate(sem, stream))) return rc;

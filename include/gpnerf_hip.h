@@ -150,13 +150,17 @@ int gpn_rgbfeat(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* r
 /* Attention part of Transformer2D (attn_norm, Attention2D, residual), transformer_network.py:74-88
  * and :107-112.  q_in [N,C], feat [N,V,C], ray_diff [N,V,4], mask [N,V] -> q_out [N,C];
  * perm [N] (or NULL): processing order from gpn_vis_order.
- * logits [N,V,C] = pre-softmax attention of the VISIBLE (point, view) pairs (mask != 0; entries of
+ * logits: C pre-softmax attention values per VISIBLE (point, view) pair (mask != 0; entries of
  * masked pairs are left unwritten: their softmax weight is exactly 0, or exactly 1/V when the
- * point has no visible view at all); stats [N,2,C] = (max_v, 1/sum_v exp) so that the per-channel
- * view softmax of line :84 is exp(logit-max)*rsum. logits/stats may be NULL. */
+ * point has no visible view at all), the row of pair (n, v) starting at logits[(n*V+v)*logits_ld];
+ * stats: (max_v [C] | 1/sum_v exp [C]) per point, row n starting at stats[n*stats_ld], so that the
+ * per-channel view softmax of line :84 is exp(logit-max)*rsum.  logits_ld >= C and stats_ld >= 2C
+ * (multiples of 4) let the caller interleave the layers (see gpn_sem_args_t); logits/stats may be
+ * NULL. */
 int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const float* feat,
                   const float* ray_diff, const float* mask, const int32_t* perm, int N, int V,
-                  float* q_out, float* logits, float* stats, gpn_stream_t stream);
+                  float* q_out, float* logits, int logits_ld, float* stats, int stats_ld,
+                  gpn_stream_t stream);
 
 /* No counterpart in the reference (scheduling aid for gpn_view_attn): perm [N] = the points sorted by
  * their set of visible views, so that 16-point tiles are homogeneous and whole (tile, view) pairs
@@ -174,17 +178,20 @@ int gpn_qpos(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* q_in
              int N, float* q_out, gpn_stream_t stream);
 
 /* Attention part of the ray Transformer, transformer_network.py:149-178 and :203-208.
- * x_in [R,S,C] -> x_out [R,S,C]; abar [R,4,S] = mean over queries of A (may be NULL);
+ * x_in [R,S,C] -> x_out [R,S,C]; abar = mean over queries of A per head (may be NULL): the 4 head
+ * values of (ray r, key s) are written to abar[(r*S+s)*abar_ld + 0..3], abar_ld >= 4;
  * weights [R,S] = head-mean of attention row 0 (transformer_network.py:216; may be NULL).
  * 1 <= S <= GPN_MAX_SAMPLES (any S; multiples of 16 waste no lanes). */
 int gpn_ray_attn(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,
-                 float* abar, float* weights, gpn_stream_t stream);
+                 float* abar, int abar_ld, float* weights, gpn_stream_t stream);
 
 typedef struct {
   int R, S, V, depth;
-  const float* logits[GPN_MAX_DEPTH]; /* per layer [N,V,C]   (from gpn_view_attn) */
-  const float* stats[GPN_MAX_DEPTH];  /* per layer [N,2,C] */
-  const float* abar[GPN_MAX_DEPTH];   /* per layer [R,4,S]   (from gpn_ray_attn) */
+  /* per-layer side outputs of gpn_view_attn / gpn_ray_attn, interleaved over the layers so that
+   * everything one (sample, view) needs is contiguous: */
+  const float* logits;                /* [N,V,depth,C]  (layer l: logits + l*C,  ld = depth*C)  */
+  const float* stats;                 /* [N,depth,2,C]  (layer l: stats + l*2C,  ld = depth*2C) */
+  const float* abar;                  /* [R,S,depth,4]  (layer l: abar + l*4,    ld = depth*4)  */
   const float* mask;                  /* [N,V] */
   /* deep-semantic source: either a materialised tensor ... */
   const float* deep_dense;            /* [N,V,512] or NULL */
@@ -196,6 +203,10 @@ typedef struct {
   float img_h, img_w;
   float* sem3d;                       /* out [N,512] = sem_feat_3d, or NULL */
   float* pre;                         /* out [R,512] = mean_s sum_l ray_sem_l (adaptor input) */
+  /* Locality hint (results do not depend on it): the rays are consecutive pixels, row-major, of an
+   * image row of ray_w pixels, ray 0 sitting at column ray_c0.  Workgroups then cover column bands
+   * over all rows of the chunk, so that one L2 sees a compact 2-D patch.  ray_w = 0: no hint. */
+  int ray_w, ray_c0;
 } gpn_sem_args_t;
 
 /* Deep-semantic aggregation of Attention2D (:90), Attention (:180-184) and GNT.forward (:335-336)

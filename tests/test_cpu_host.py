@@ -53,7 +53,7 @@ def test_argument_errors_come_back_as_messages():
     L = _lib.lib()
     rc = L.gpn_sample_along_ray(None, None, 1.0, 2.0, 4, 8, 0, None, None, None, None)
     assert rc == -1 and b"null pointer" in L.gpn_last_error()
-    rc = L.gpn_ray_attn(None, None, 0, 48, None, None, None, None)
+    rc = L.gpn_ray_attn(None, None, 0, 48, None, None, 4, None, None)
     assert rc == 0  # empty batch is a no-op
     with pytest.raises(RuntimeError, match="gpn_sample_along_ray failed"):
         _lib.check(L.gpn_sample_along_ray(None, None, 1.0, 2.0, 4, 8, 0, None, None, None, None),

@@ -281,7 +281,8 @@ def test_gnt_stages(dev, net, prec, S):
         q_in = f((rec["q0"] if l == 0 else rec["q_ray"][l - 1]).reshape(N, 64))
         qo, lg, stt = e(N, 64), e(N, V, 64), e(N, 2, 64)
         _lib.check(L.gpn_view_attn(C.byref(W.view[l]), _lib.ptr(q_in), _lib.ptr(feat_ref), _lib.ptr(rd),
-                                   _lib.ptr(mk), None, N, V, _lib.ptr(qo), _lib.ptr(lg), _lib.ptr(stt), st), "view")
+                                   _lib.ptr(mk), None, N, V, _lib.ptr(qo), _lib.ptr(lg), 64,
+                                   _lib.ptr(stt), 128, st), "view")
         errs["view_attn%d" % l] = rel(qo, rec["q_view_attn"][l].reshape(N, 64))
         # same launch in visibility-sorted order: bit-identical outputs
         perm = torch.empty(N, dtype=torch.int32, device=dev)
@@ -296,8 +297,8 @@ def test_gnt_stages(dev, net, prec, S):
         qo2, lg2, stt2 = e(N, 64), torch.zeros_like(lg), e(N, 2, 64)
         lg.masked_fill_(mk.reshape(N, V, 1) == 0, 0.0)  # unwritten (masked) entries -> 0 on both sides
         _lib.check(L.gpn_view_attn(C.byref(W.view[l]), _lib.ptr(q_in), _lib.ptr(feat_ref), _lib.ptr(rd),
-                                   _lib.ptr(mk), _lib.ptr(perm), N, V, _lib.ptr(qo2), _lib.ptr(lg2),
-                                   _lib.ptr(stt2), st), "view-perm")
+                                   _lib.ptr(mk), _lib.ptr(perm), N, V, _lib.ptr(qo2), _lib.ptr(lg2), 64,
+                                   _lib.ptr(stt2), 128, st), "view-perm")
         lg2.masked_fill_(mk.reshape(N, V, 1) == 0, 0.0)
         assert torch.equal(qo, qo2) and torch.equal(stt, stt2) and torch.equal(lg, lg2), \
             "visibility-sorted order changed the results"
@@ -322,12 +323,13 @@ def test_gnt_stages(dev, net, prec, S):
             x_in = rec["q_pos"][l // 2]
         else:
             x_in = rec["q_view"][l]
-        xo, ab, wt = e(R, S, 64), e(R, 4, S), e(R, S)
+        xo, ab, wt = e(R, S, 64), torch.full((R, S, 6), -7.0, device=dev), e(R, S)
         x_in_d = f(x_in)
         _lib.check(L.gpn_ray_attn(C.byref(W.ray[l]), _lib.ptr(x_in_d), R, S, _lib.ptr(xo), _lib.ptr(ab),
-                                  _lib.ptr(wt), st), "ray")
+                                  6, _lib.ptr(wt), st), "ray")  # abar rows with leading dimension 6
         errs["ray_attn%d" % l] = rel(xo, rec["q_ray_attn"][l])
-        errs["abar%d" % l] = rel(ab, rec["A"][l].mean(dim=2))
+        errs["abar%d" % l] = rel(ab[:, :, :4], rec["A"][l].mean(dim=2).permute(0, 2, 1))
+        assert bool((ab[:, :, 4:] == -7.0).all()), "gpn_ray_attn wrote outside its 4 abar columns"
         errs["weights%d" % l] = rel(wt, rec["A"][l].mean(dim=1)[:, 0])
     torch.cuda.synchronize()
     print("stage errors [%s, S=%d]: max %.2e (%s)" % (prec, S, max(errs.values()),

@@ -76,10 +76,9 @@ def ray_chunk(scene, rank, world, dev):
     start = ((r0 + r1) // 2) * scene.W
     start = min(start, scene.H * scene.W - CHUNK)
     sl = slice(start, start + CHUNK)
-    rb = {"ray_o": scene.rays_o[sl].to(dev), "ray_d": scene.rays_d[sl].to(dev),
-          "depth_range": scene.depth_range, "camera": scene.camera,
-          "src_rgbs": scene.src_rgbs, "src_cameras": scene.src_cameras}
-    return rb, (scene.W, start % scene.W)  # row hint, as render_single_image passes it per chunk
+    return {"ray_o": scene.rays_o[sl].to(dev), "ray_d": scene.rays_d[sl].to(dev),
+            "depth_range": scene.depth_range, "camera": scene.camera,
+            "src_rgbs": scene.src_rgbs, "src_cameras": scene.src_cameras}
 
 
 def cpu_baseline(scene, rb, n_rays):
@@ -109,7 +108,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-rays", type=int, default=1536, help="rays of the CPU baseline sample (0: skip)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-stage time table to stderr")
-    ap.add_argument("--no-row-hint", action="store_true", help="render_rays without the row-width hint")
     ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16x3"),
                     help="arithmetic of the GNT linear layers (see include/gpnerf_hip.h)")
     a = ap.parse_args()
@@ -134,16 +132,14 @@ def main():
     scene, net, projector = build(dev)
     net.precision = a.precision
     model = types.SimpleNamespace(net_coarse=net, net_fine=None)
-    rb, row_hint = ray_chunk(scene, rank, world, dev)
-    if a.no_row_hint:
-        row_hint = None
+    rb = ray_chunk(scene, rank, world, dev)
     tile_w = 2 * (3 + 1 + 512)
     gathered = torch.empty((world * CHUNK, tile_w), device=dev) if world > 1 else None
 
     def step():
         ret = render_rays(rb, model, scene.featmaps, scene.deep, projector, N_samples=N_SAMPLES,
                           inv_uniform=True, N_importance=N_IMPORTANCE, det=True, ret_alpha=True,
-                          single_net=True, row_hint=row_hint)
+                          single_net=True)
         if world > 1:  # rgb / depth / semantic tiles of both levels, one collective
             c, f = ret["outputs_coarse"], ret["outputs_fine"]
             tile = torch.cat([c["rgb"], c["depth"][:, None], c["feats_out"],

@@ -73,8 +73,7 @@ class SemArgs(C.Structure):
                 ("deep_map", C.c_void_p), ("deep_h", C.c_int), ("deep_w", C.c_int),
                 ("xyz", C.c_void_p), ("proj", C.c_void_p),
                 ("img_h", C.c_float), ("img_w", C.c_float),
-                ("sem3d", C.c_void_p), ("pre", C.c_void_p),
-                ("ray_w", C.c_int), ("ray_c0", C.c_int)]
+                ("sem3d", C.c_void_p), ("pre", C.c_void_p)]
 
 
 _P = C.c_void_p

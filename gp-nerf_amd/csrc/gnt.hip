@@ -534,9 +534,10 @@ struct RayCfg {
   static_assert(THREADS <= 1024, "too many waves per workgroup");
 };
 
-// Split (bf16x3) mode keeps the same LDS budget with 16-byte units [hi(4) | mid(4)]:
-//   Ks: unit (key, head h, g) = channels 16h+4g..+3 of the key       (row stride 17 units)
-//   Vt: unit (channel, key tile kt, g) = keys 16kt+4g..+3 of channel (row stride 4*NT+1 units)
+// Split (bf16x3) mode keeps the same LDS budget with 16-byte units [hi(4) | mid(4)], fragment-major
+// (64 consecutive units = the A fragment of one MFMA, read at [block + lane]: conflict-free):
+//   Ks: unit (key 16kt+j, head h, g) = channels 16h+4g..+3 of the key     at (4kt + h)*64 + 16g + j
+//   Vt: unit (channel 16h+j, key tile kt, g) = keys 16kt+4g..+3           at (NT*h + kt)*64 + 16g + j
 // so that one unit is the A operand of both MFMAs of a product: against B = [x_hi | x_hi] it yields
 // a_hi*x_hi + a_mid*x_hi, against B = [x_mid | 0] it yields a_hi*x_mid.
 template <int NT, bool SPL>
@@ -548,7 +549,6 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
   // computed on clamped data and never stored.
   using Cfg = RayCfg<NT>;
   constexpr int SP = Cfg::SP, RPW = Cfg::RPW, LDV = Cfg::LDV, NTHR = Cfg::THREADS;
-  constexpr int KU = 17, VU = 4 * NT + 1;  // row strides of the split images, in 16-byte units
   float* Wq = smem;
   float* Wk = Wq + 64 * LDW;
   float* Wv = Wk + 64 * LDW;
@@ -609,11 +609,11 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
       for (int M = 0; M < 4; ++M) kT[M] = f4_zero(), vN[M] = f4_zero();
       lin_Sx<4, 4>(Wk, xs, kT, lane);
 #pragma unroll
-      for (int M = 0; M < 4; ++M) Ku_s[(16 * t + j) * KU + 4 * M + g] = split4(kT[M]);
+      for (int M = 0; M < 4; ++M) Ku_s[(4 * t + M) * 64 + lane] = split4(kT[M]);
       // V in normal orientation: lane (j, g) holds V[key 16t + 4g + reg][channel 16M + j]
       lin_Sx<4, 4, false>(Wv, xs, vN, lane);
 #pragma unroll
-      for (int M = 0; M < 4; ++M) Vu_s[(16 * M + j) * VU + 4 * t + g] = split4(vN[M]);
+      for (int M = 0; M < 4; ++M) Vu_s[(NT * M + t) * 64 + lane] = split4(vN[M]);
     } else {
       lin_T<4, 4>(Wq, LDW, xn, qT, lane);
       {
@@ -654,7 +654,7 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
         }
         bf8 ku[NT];
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) ku[kt] = Ku_s[(16 * kt + j) * KU + 4 * h + g];
+        for (int kt = 0; kt < NT; ++kt) ku[kt] = Ku_s[(4 * kt + h) * 64 + lane];
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) sT[kt] = mfma_bf(ku[kt], qb2, f4_zero());
 #pragma unroll
@@ -709,7 +709,7 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
       if constexpr (SPL) {
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
-          const bf8 vu = Vu_s[(16 * h + j) * VU + 4 * kt + g];
+          const bf8 vu = Vu_s[(NT * h + kt) * 64 + lane];
           const bf8 ps = split4(sT[kt]);
           bf8 pb1, pb2;
 #pragma unroll
@@ -798,18 +798,10 @@ k_sem(gpn_sem_args_t a) {
     for (int i = tid; i < V * 12; i += SEM_RAYS * 64) sP[i] = a.proj[(i / 12) * 16 + (i % 12)];
   }
   __syncthreads();
-  // ray of this wave: 8 consecutive rays, or (with the row hint) 8 consecutive pixels of one image
-  // row, the workgroups of an XCD covering a band of columns over all rows of the chunk
-  int r = blk * SEM_RAYS + wave;
-  bool rvalid = r < a.R;
-  if (a.ray_w > 0) {
-    const int rows = (a.ray_c0 + a.R + a.ray_w - 1) / a.ray_w;
-    const int cg = blk / rows, row = blk - cg * rows, col = cg * SEM_RAYS + wave;
-    r = row * a.ray_w + col - a.ray_c0;
-    rvalid = col < a.ray_w && r >= 0 && r < a.R;
-  }
-  if (!__syncthreads_or(rvalid)) return;  // padding group of the banded layout
-  const int rc = __builtin_amdgcn_readfirstlane(rvalid ? r : (r < 0 ? 0 : a.R - 1));
+  // (Banding the workgroups of an XCD into 2-D pixel patches was measured: no gain over 1-D runs.)
+  const int r = blk * SEM_RAYS + wave;
+  const bool rvalid = r < a.R;
+  const int rc = rvalid ? r : a.R - 1;
   const int c8 = lane * 8, head = lane >> 4;  // lane == channel group
   f4 acc2a = f4_zero(), acc2b = f4_zero();
   const size_t rs = (size_t)a.deep_w * GPN_SEM;
@@ -1216,12 +1208,7 @@ extern "C" int gpn_sem_aggregate(const gpn_sem_args_t* a, gpn_stream_t stream) {
   GPN_REQUIRE(aligned16(a->pre) && aligned16(a->sem3d), "gpn_sem_aggregate: outputs must be aligned");
   if (a->R == 0) return GPN_OK;
   GpnStageTimer timer_k_sem_(GPN_ST_SEM, (hipStream_t)stream);
-  int groups = gpn_ceil_div(a->R, SEM_RAYS);
-  if (a->ray_w > 0) {
-    GPN_REQUIRE(a->ray_c0 >= 0 && a->ray_c0 < a->ray_w, "gpn_sem_aggregate: ray_c0 must be in [0, ray_w)");
-    const long long rows = ((long long)a->ray_c0 + a->R + a->ray_w - 1) / a->ray_w;
-    groups = (int)(rows * gpn_ceil_div(a->ray_w, SEM_RAYS));
-  }
+  const int groups = gpn_ceil_div(a->R, SEM_RAYS);
   const dim3 grid(groups), block(SEM_RAYS * 64);
   hipStream_t st = (hipStream_t)stream;
   switch (a->depth) {

@@ -187,9 +187,12 @@ __device__ __forceinline__ void stage_vector(float* dst, int padded, const float
 //
 // K-step of 32 = a PAIR of T-tiles (2P, 2P+1).  Lane (j, g) supplies, as the 8 bf16 of its B
 // fragment, its own registers of the two tiles: elements 0-3 = channels 32P+4g+r, elements 4-7 =
-// channels 32P+16+4g+r.  The weight image in LDS stores, per output row, 16-byte units
-// [pair P][g] = the 8 matching weight columns in that order, hi units first, then mid units
-// (row stride (8*KP+1) units, odd -> rows spread over all bank slots).
+// channels 32P+16+4g+r.  The weight image in LDS is made of 16-byte units (the 8 matching weight
+// columns of one output row, in that order), laid out FRAGMENT-MAJOR:
+//   unit(row 16M+i, pair P, piece hm (0 = hi, 1 = mid), g)  at  ((M*KP + P)*2 + hm)*64 + 16*g + i
+// so the A fragment of one MFMA is 64 consecutive units read at [block + lane]: each of
+// ds_read_b128's four 16-lane groups then covers all 16 slots of the 256-byte bank row (a padded
+// row-major image is 2-way conflicted on one slot per group: measured 45 % extra LDS cycles).
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 struct XS {
   bf8 hi, mid;
@@ -216,7 +219,7 @@ __device__ __forceinline__ XS split8(f4 a, f4 b) {
 
 // floats of LDS taken by the weight image of a [prow x 16*kt] matrix
 __host__ __device__ constexpr int wimg_floats(bool split, int prow, int kt, int ld) {
-  return split ? prow * (((kt + 1) / 2) * 8 + 1) * 4 : prow * ld;
+  return split ? ((prow + 15) / 16) * ((kt + 1) / 2) * 2 * 64 * 4 : prow * ld;
 }
 
 // [hi(a) | mid(a)] of four fp32 values as one 16-byte unit
@@ -235,8 +238,8 @@ __device__ __forceinline__ bf8 split4(f4 a) {
 // comes out in normal orientation: lane (j, g) holds Y[point 4g + reg][channel 16M + j].
 template <int KT, int MT, bool TRANSPOSED = true>
 __device__ __forceinline__ void lin_Sx(const float* Wf, const XS* xs, f4* y, int lane) {
-  constexpr int KP = (KT + 1) / 2, RS = KP * 8 + 1;
-  const bf8* wp = reinterpret_cast<const bf8*>(Wf) + (lane & 15) * RS + (lane >> 4);
+  constexpr int KP = (KT + 1) / 2;
+  const bf8* wp = reinterpret_cast<const bf8*>(Wf) + lane;
   constexpr int MC = MT < 4 ? MT : 4;
   static_assert(MT % MC == 0, "MT must be a multiple of the accumulator chunk");
 #pragma unroll
@@ -244,8 +247,8 @@ __device__ __forceinline__ void lin_Sx(const float* Wf, const XS* xs, f4* y, int
     bf8 wh[MC], wm[MC];
 #pragma unroll
     for (int m = 0; m < MC; ++m) {
-      wh[m] = wp[(16 * (M0 + m)) * RS];
-      wm[m] = wp[(16 * (M0 + m)) * RS + KP * 4];
+      wh[m] = wp[((M0 + m) * KP) * 128];
+      wm[m] = wp[((M0 + m) * KP) * 128 + 64];
     }
 #pragma unroll
     for (int P = 0; P < KP; ++P) {
@@ -253,8 +256,8 @@ __device__ __forceinline__ void lin_Sx(const float* Wf, const XS* xs, f4* y, int
       if (P + 1 < KP) {
 #pragma unroll
         for (int m = 0; m < MC; ++m) {
-          nh[m] = wp[(16 * (M0 + m)) * RS + (P + 1) * 4];
-          nm[m] = wp[(16 * (M0 + m)) * RS + KP * 4 + (P + 1) * 4];
+          nh[m] = wp[((M0 + m) * KP + P + 1) * 128];
+          nm[m] = wp[((M0 + m) * KP + P + 1) * 128 + 64];
         }
       }
       // small terms first, so that they are not rounded away against the large one
@@ -301,7 +304,7 @@ __device__ __forceinline__ void lin(const float* W, int ldw, const f4* x, f4* y,
 // Build the split image of a row-major [rows, cols] fp32 matrix, zero-padded to [prow, 16*kt].
 __device__ __forceinline__ void stage_split(float* dstf, const float* __restrict__ src, int rows,
                                             int cols, int prow, int kt, int tid, int nthreads) {
-  const int KP = (kt + 1) / 2, RS = KP * 8 + 1, upr = KP * 4;
+  const int KP = (kt + 1) / 2, upr = KP * 4;
   bf8* dst = reinterpret_cast<bf8*>(dstf);
   const bool vec = (cols & 3) == 0;
   for (int idx = tid; idx < prow * upr; idx += nthreads) {
@@ -322,8 +325,9 @@ __device__ __forceinline__ void stage_split(float* dstf, const float* __restrict
       }
     }
     const XS s = split8(a, b);
-    dst[row * RS + u] = s.hi;
-    dst[row * RS + upr + u] = s.mid;
+    const int blk = (((row >> 4) * KP + P) * 2) * 64 + 16 * g + (row & 15);
+    dst[blk] = s.hi;
+    dst[blk + 64] = s.mid;
   }
 }
 

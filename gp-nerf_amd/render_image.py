@@ -17,7 +17,7 @@ _SHARED_KEYS = ("camera", "depth_range", "src_rgbs", "src_cameras", "labels", "s
 
 def _render_chunks(ray_batch, model, projector, chunk_size, N_samples, inv_uniform, N_importance,
                    det, white_bkgd, featmaps, deep_semantics, ret_alpha, single_net, start, stop,
-                   feats_out_3d=True, row_width=0):
+                   feats_out_3d=True):
     """Chunk loop (reference render_image.py:39-85) over rays [start, stop); results stay on the
     device: {'outputs_coarse': {k: [chunks]}, 'outputs_fine': ... or None}."""
     acc = OrderedDict([("outputs_coarse", OrderedDict()), ("outputs_fine", OrderedDict())])
@@ -34,8 +34,7 @@ def _render_chunks(ray_batch, model, projector, chunk_size, N_samples, inv_unifo
         ret = render_rays(chunk, model, featmaps, ref_deep_semantics=deep_semantics,
                           projector=projector, N_samples=N_samples, inv_uniform=inv_uniform,
                           N_importance=N_importance, det=det, white_bkgd=white_bkgd,
-                          ret_alpha=ret_alpha, single_net=single_net, feats_out_3d=feats_out_3d,
-                          row_hint=(row_width, i % row_width) if row_width > 0 else None)
+                          ret_alpha=ret_alpha, single_net=single_net, feats_out_3d=feats_out_3d)
         for lvl in ("outputs_coarse", "outputs_fine"):
             if ret[lvl] is None:
                 acc[lvl] = None
@@ -88,11 +87,10 @@ def render_single_image(
     tensors: rgb [H',W',3], depth [H',W'], weights [H',W',S], feats_out [H',W',512],
     feats_out_3d [H',W',S*512] (skipped with the extension flag feats_out_3d=False)."""
     N_rays = ray_batch["ray_o"].shape[0]
-    Hs, Ws = _strided_hw(ray_sampler, render_stride)
     acc = _render_chunks(ray_batch, model, projector, chunk_size, N_samples, inv_uniform,
                          N_importance, det, white_bkgd, featmaps, deep_semantics, ret_alpha,
-                         single_net, 0, N_rays, feats_out_3d,
-                         row_width=Ws if N_rays == Hs * Ws else 0)
+                         single_net, 0, N_rays, feats_out_3d)
+    Hs, Ws = _strided_hw(ray_sampler, render_stride)
     return _merge(acc, Hs, Ws)
 
 
@@ -123,10 +121,8 @@ def render_image_sharded(ray_sampler, ray_batch, model, projector, chunk_size, N
     rows, parts = shard_rows(Hs, G)
     r0, r1 = parts[rank]
     fn = render_fn or _render_chunks
-    kw = {} if render_fn else {"row_width": Ws}
     acc = fn(ray_batch, model, projector, chunk_size, N_samples, inv_uniform, N_importance, det,
-             white_bkgd, featmaps, deep_semantics, ret_alpha, single_net, r0 * Ws, r1 * Ws, False,
-             **kw)
+             white_bkgd, featmaps, deep_semantics, ret_alpha, single_net, r0 * Ws, r1 * Ws, False)
     dev = ray_batch["ray_o"].device
     out = OrderedDict()
     for lvl in ("outputs_coarse", "outputs_fine"):

@@ -110,14 +110,13 @@ def raw2outputs(raw, z_vals, mask, white_bkgd=False):
                         ("mask", rmask > 0.5), ("alpha", alpha), ("z_vals", z_vals)])
 
 
-def _gnt_pass(net, projector, sv, pts, z_vals, ray_d, ret_alpha, want_3d=True, row_hint=None):
+def _gnt_pass(net, projector, sv, pts, z_vals, ray_d, ret_alpha, want_3d=True):
     """One coarse/fine pass on the fused path: project+gather (35 ch), GNT, semantic aggregation
     straight from the NHWC deep-semantic maps (no [R,S,V,512] tensor)."""
     rgb_feat, ray_diff, mask = projector.compute_fused(pts, sv)
     deep_map = None
     if sv.deep is not None:
-        deep_map = dict(map=sv.deep, proj=sv.proj, img_h=sv.img_h, img_w=sv.img_w,
-                        row_hint=row_hint)
+        deep_map = dict(map=sv.deep, proj=sv.proj, img_h=sv.img_h, img_w=sv.img_w)
     out, depth, feats_out, feats_out_3d = net.run(
         rgb_feat, ray_diff, mask, pts, ray_d, z_vals=z_vals if ret_alpha else None,
         deep_map=deep_map, want_sem3d=want_3d)
@@ -145,15 +144,12 @@ def render_rays(
     save_feature=False,
     model_type="gnt",
     feats_out_3d=True,
-    row_hint=None,
 ):
     """reference render_ray.py:194-300.  Returns {'outputs_coarse': {...}, 'outputs_fine': {...}} with
     keys rgb / weights / depth / feats_out / feats_out_3d (None where the reference returns None).
 
     `feats_out_3d=False` (extension, default keeps the reference behaviour) skips the [R,S,512]
-    tensor, which the reference computes and copies to the host but never reads in eval.
-    `row_hint=(row_width, column_of_ray_0)` (extension) tells the semantic aggregation that the rays
-    are consecutive row-major pixels; it only changes the order rays are processed in."""
+    tensor, which the reference computes and copies to the host but never reads in eval."""
     ret = {"outputs_coarse": None, "outputs_fine": None}
     ray_o, ray_d = ray_batch["ray_o"], ray_batch["ray_d"]
     pts, z_vals = sample_along_camera_ray(ray_o=ray_o, ray_d=ray_d,
@@ -165,7 +161,7 @@ def render_rays(
 
     if fused:
         ret["outputs_coarse"] = _gnt_pass(model.net_coarse, projector, sv, pts, z_vals, ray_d,
-                                          ret_alpha, feats_out_3d, row_hint)
+                                          ret_alpha, feats_out_3d)
     else:
         rgb_feat, deep, ray_diff, mask = projector.compute(
             pts, ray_batch["camera"], ray_batch["src_rgbs"], ray_batch["src_cameras"],
@@ -193,7 +189,7 @@ def render_rays(
         net = model.net_coarse if single_net else model.net_fine
         if hasattr(net, "run"):
             ret["outputs_fine"] = _gnt_pass(net, projector, sv, pts, z_vals, ray_d, True,
-                                            feats_out_3d, row_hint)
+                                            feats_out_3d)
         else:
             rgb_feat, deep, ray_diff, mask = projector.compute(
                 pts, ray_batch["camera"], ray_batch["src_rgbs"], ray_batch["src_cameras"],

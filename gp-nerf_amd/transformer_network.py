@@ -216,8 +216,6 @@ class GNT(nn.Module):
                 sem.deep_map, sem.deep_h, sem.deep_w = _lib.ptr(m), m.shape[1], m.shape[2]
                 sem.xyz, sem.proj = _lib.ptr(pts), _lib.ptr(deep_map["proj"])
                 sem.img_h, sem.img_w = deep_map["img_h"], deep_map["img_w"]
-                if deep_map.get("row_hint"):  # (row width, column of ray 0): locality hint only
-                    sem.ray_w, sem.ray_c0 = int(deep_map["row_hint"][0]), int(deep_map["row_hint"][1])
         _lib.check(_lib.lib().gpn_gnt_forward(
             C.byref(W), _lib.ptr(rgb_feat), _lib.ptr(ray_diff), _lib.ptr(mask), _lib.ptr(pts),
             _lib.ptr(ray_d), _lib.ptr(z_vals), R, S, V, C.byref(sem) if sem is not None else None,

@@ -203,10 +203,6 @@ typedef struct {
   float img_h, img_w;
   float* sem3d;                       /* out [N,512] = sem_feat_3d, or NULL */
   float* pre;                         /* out [R,512] = mean_s sum_l ray_sem_l (adaptor input) */
-  /* Locality hint (results do not depend on it): the rays are consecutive pixels, row-major, of an
-   * image row of ray_w pixels, ray 0 sitting at column ray_c0.  Workgroups then cover column bands
-   * over all rows of the chunk, so that one L2 sees a compact 2-D patch.  ray_w = 0: no hint. */
-  int ray_w, ray_c0;
 } gpn_sem_args_t;
 
 /* Deep-semantic aggregation of Attention2D (:90), Attention (:180-184) and GNT.forward (:335-336)

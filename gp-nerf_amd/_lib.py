@@ -18,6 +18,7 @@ MAX_SAMPLES = 128
 EMB = 128
 SEM = 512
 NETWIDTH = 64
+VIEW_FOLD_FLOATS = 64 * 64 + 16 * 96 + 16
 
 _f = C.POINTER(C.c_float)
 
@@ -33,7 +34,7 @@ class ViewLayer(C.Structure):
                 ("q", Linear), ("k", Linear), ("v", Linear),
                 ("pos0", Linear), ("pos2", Linear),
                 ("attn0", Linear), ("attn2", Linear),
-                ("out", Linear)]
+                ("out", Linear), ("folded", C.c_void_p)]
 
 
 class RayLayer(C.Structure):
@@ -93,6 +94,7 @@ _SIGS = {
                               _P, _P, _P]),
     "gpn_view_attn": (C.c_int, [C.POINTER(ViewLayer), _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P,
                                 C.c_int, _P, C.c_int, _P]),
+    "gpn_view_fold": (C.c_int, [C.POINTER(ViewLayer), _P, _P]),
     "gpn_vis_order_scratch_bytes": (C.c_size_t, []),
     "gpn_vis_order": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P]),
     "gpn_ff": (C.c_int, [_P, _P, C.POINTER(Linear), C.POINTER(Linear), _P, C.c_int, _P, _P]),

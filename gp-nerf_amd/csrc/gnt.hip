@@ -28,9 +28,13 @@
 #ifndef QP_TPB
 #define QP_TPB 512
 #endif
+#ifndef FF_NTL
+#define FF_NTL 2  // point tiles per wave of the split-mode feed-forward kernel
+#endif
 #define LDW 68  // padded leading dimension of a 64-wide weight matrix in LDS
 
 extern __shared__ __attribute__((aligned(16))) float smem[];
+
 
 static int set_lds_limit(const void* fn, size_t bytes) {
   if (bytes <= 64 * 1024) return GPN_OK;
@@ -235,6 +239,7 @@ k_vis_scatter(const float* __restrict__ mask, int N, int V, int* __restrict__ cu
 #define VA_LD8 20
 struct ViewLds {
   float *Wq, *Wk, *Wv, *Wo, *P2, *A0, *A2, *P0, *bP0, *bP2, *bA0, *bA2, *bO, *gam, *bet;
+  float *AF, *c0;  // folded mode: (A0 Wk | A0 P2) image and the constant A0 b_pos2 + b_attn0
 };
 template <bool SPL>
 __device__ __forceinline__ ViewLds view_lds(float* s) {
@@ -254,14 +259,47 @@ __device__ __forceinline__ ViewLds view_lds(float* s) {
   L.bO = L.bA2 + 64;
   L.gam = L.bO + 64;
   L.bet = L.gam + 64;
+  L.c0 = L.bet + 64;
+  L.AF = L.c0 + 16;
   return L;
 }
 constexpr int view_lds_floats(bool spl) {
   return 4 * wimg_floats(spl, 64, 4, LDW) + 2 * wimg_floats(spl, 64, 1, VA_LD8) +
-         wimg_floats(spl, 16, 4, LDW) + 64 + 16 + 64 + 16 + 64 * 4;
+         wimg_floats(spl, 16, 4, LDW) + 64 + 16 + 64 + 16 + 64 * 4 + 16 +
+         (spl ? wimg_floats(true, 16, 6, 0) : 0);
 }
 
-template <bool SPL>
+// Folded weight products of one Attention2D layer (gpn_view_fold in the header), fp64 accumulation.
+#define FOLD_VK 0
+#define FOLD_AF (64 * 64)
+#define FOLD_C0 (64 * 64 + 16 * 96)
+__global__ void __launch_bounds__(256)
+k_view_fold(gpn_view_layer_t Lw, float* __restrict__ out) {
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < GPN_VIEW_FOLD_FLOATS; idx += gridDim.x * 256) {
+    double acc = 0.0;
+    if (idx < FOLD_AF) {  // (Wv Wk)[i][j]
+      const int i = idx >> 6, jj = idx & 63;
+      for (int c = 0; c < 64; ++c) acc += (double)Lw.v.w[i * 64 + c] * (double)Lw.k.w[c * 64 + jj];
+    } else if (idx < FOLD_C0) {
+      const int r = (idx - FOLD_AF) / 96, c = (idx - FOLD_AF) % 96;
+      if (r < 8 && c < 64) {         // (A0 Wk)[r][c]
+        for (int m = 0; m < 64; ++m) acc += (double)Lw.attn0.w[r * 64 + m] * (double)Lw.k.w[m * 64 + c];
+      } else if (r < 8 && c < 72) {  // (A0 P2)[r][c-64]
+        for (int m = 0; m < 64; ++m) acc += (double)Lw.attn0.w[r * 64 + m] * (double)Lw.pos2.w[m * 8 + (c - 64)];
+      }
+    } else {
+      const int r = idx - FOLD_C0;
+      if (r < 8) {
+        acc = Lw.attn0.b ? (double)Lw.attn0.b[r] : 0.0;
+        if (Lw.pos2.b)
+          for (int m = 0; m < 64; ++m) acc += (double)Lw.attn0.w[r * 64 + m] * (double)Lw.pos2.b[m];
+      }
+    }
+    out[idx] = (float)acc;
+  }
+}
+
+template <bool SPL, bool FOLD>
 __global__ void __launch_bounds__(VA_TPB)
 k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __restrict__ feat,
             const float* __restrict__ ray_diff, const float* __restrict__ mask,
@@ -270,8 +308,15 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
   const ViewLds L = view_lds<SPL>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   stage_w<SPL>(L.Wq, LDW, Lw.q.w, 64, 64, 64, 4, tid, VA_TPB);
-  stage_w<SPL>(L.Wk, LDW, Lw.k.w, 64, 64, 64, 4, tid, VA_TPB);
-  stage_w<SPL>(L.Wv, LDW, Lw.v.w, 64, 64, 64, 4, tid, VA_TPB);
+  static_assert(SPL || !FOLD, "the folded algorithm exists in split mode only");
+  if constexpr (FOLD) {  // Wv slot holds Wv Wk; k itself is never formed
+    stage_w<SPL>(L.Wv, LDW, Lw.folded + FOLD_VK, 64, 64, 64, 4, tid, VA_TPB);
+    stage_w<SPL>(L.AF, 0, Lw.folded + FOLD_AF, 16, 96, 16, 6, tid, VA_TPB);
+    stage_vector(L.c0, 16, Lw.folded + FOLD_C0, 16, tid, VA_TPB);
+  } else {
+    stage_w<SPL>(L.Wk, LDW, Lw.k.w, 64, 64, 64, 4, tid, VA_TPB);
+    stage_w<SPL>(L.Wv, LDW, Lw.v.w, 64, 64, 64, 4, tid, VA_TPB);
+  }
   stage_w<SPL>(L.Wo, LDW, Lw.out.w, 64, 64, 64, 4, tid, VA_TPB);
   stage_w<SPL>(L.P2, VA_LD8, Lw.pos2.w, 64, 8, 64, 1, tid, VA_TPB);
   stage_w<SPL>(L.A0, LDW, Lw.attn0.w, 8, 64, 16, 4, tid, VA_TPB);
@@ -309,6 +354,12 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
       for (int M = 0; M < 4; ++M) qp[M] = f4_zero();
       lin<SPL, 4, 4>(L.Wq, LDW, qn, qp, lane);
     }
+    f4 aq = f4_zero();  // folded mode: A0 b_pos2 + b_attn0 - A0 q  (the per-point part of attn_fc[0])
+    if constexpr (FOLD) {
+      f4 t = f4_zero();
+      lin<SPL, 4, 1>(L.A0, LDW, qp, &t, lane);
+      aq = ld4(L.c0 + 4 * g) - t;
+    }
     f4 mrun[4], lrun[4], acc[4];
 #pragma unroll
     for (int M = 0; M < 4; ++M) {
@@ -330,11 +381,14 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
     }
     live = __builtin_amdgcn_readfirstlane(live);
     const float* frow = feat + (size_t)nc * V * C64 + 4 * g;
+    const float* rdrow = ray_diff + (size_t)nc * V * 4 + g;
     f4 fcur[4];
+    float rdcur;
     {
       const int v0 = live ? __builtin_ctz(live) : 0;
 #pragma unroll
       for (int T = 0; T < 4; ++T) fcur[T] = ld4(frow + (size_t)v0 * C64 + 16 * T);
+      rdcur = rdrow[v0 * 4];
     }
 
     while (live) {
@@ -344,32 +398,48 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
       const int vn = live ? __builtin_ctz(live) : v;
 #pragma unroll
       for (int T = 0; T < 4; ++T) fnext[T] = ld4(frow + (size_t)vn * C64 + 16 * T);
+      const float rd = rdcur;
+      rdcur = rdrow[vn * 4];
       const float mk = (vis >> v) & 1u ? 1.0f : 0.0f;
-      const float rd = ray_diff[((size_t)nc * V + v) * 4 + g];
 
-      f4 k[4], val[4];
+      f4 val[4], pos[4], a[4];
 #pragma unroll
-      for (int M = 0; M < 4; ++M) k[M] = f4_zero(), val[M] = f4_zero();
-      lin<SPL, 4, 4>(L.Wk, LDW, fcur, k, lane);   // k = k_fc(feat)
-      lin<SPL, 4, 4>(L.Wv, LDW, k, val, lane);    // v = v_fc(k)   (reference quirk, :77)
-      // pos = pos_fc(ray_diff): 4 -> 8 (ReLU) -> 64
-      f4 ph = mfma16(p0w, rd, ld4(L.bP0 + 4 * g));
-      ph = f4_relu(ph);
-      f4 pos[4];
+      for (int M = 0; M < 4; ++M) {
+        val[M] = f4_zero();
+        pos[M] = ld4(L.bP2 + 16 * M + 4 * g);
+        a[M] = ld4(L.bA2 + 16 * M + 4 * g);
+      }
+      // pos hidden layer: 4 -> 8 (ReLU), one fp32 MFMA
+      f4 ph = f4_relu(mfma16(p0w, rd, ld4(L.bP0 + 4 * g)));
+      if constexpr (FOLD) {
+        // v = (Wv Wk) f ; pos = P2 h + b ; attn hidden = (A0 Wk) f + (A0 P2) h + aq : every product
+        // reads the split of f and h made once here
+        XS xs[3];
+        xs[0] = split8(fcur[0], fcur[1]);
+        xs[1] = split8(fcur[2], fcur[3]);
+        xs[2] = split8(ph, f4_zero());
+        lin_Sx<4, 4>(L.Wv, xs, val, lane);
+        lin_Sx<1, 4>(L.P2, xs + 2, pos, lane);
+        f4 ah = aq;
+        lin_Sx<6, 1>(L.AF, xs, &ah, lane);
+        ah = f4_relu(ah);
+        lin<SPL, 1, 4>(L.A2, VA_LD8, &ah, a, lane);
+      } else {
+        f4 k[4];
 #pragma unroll
-      for (int M = 0; M < 4; ++M) pos[M] = ld4(L.bP2 + 16 * M + 4 * g);
-      lin<SPL, 1, 4>(L.P2, VA_LD8, &ph, pos, lane);
-      // attn = attn_fc(k - q + pos): 64 -> 8 (ReLU) -> 64
-      f4 ain[4];
+        for (int M = 0; M < 4; ++M) k[M] = f4_zero();
+        lin<SPL, 4, 4>(L.Wk, LDW, fcur, k, lane);   // k = k_fc(feat)
+        lin<SPL, 4, 4>(L.Wv, LDW, k, val, lane);    // v = v_fc(k)   (reference quirk, :77)
+        lin<SPL, 1, 4>(L.P2, VA_LD8, &ph, pos, lane);  // pos = pos_fc(ray_diff): 4 -> 8 -> 64
+        // attn = attn_fc(k - q + pos): 64 -> 8 (ReLU) -> 64
+        f4 ain[4];
 #pragma unroll
-      for (int M = 0; M < 4; ++M) ain[M] = k[M] - qp[M] + pos[M];
-      f4 ah = ld4(L.bA0 + 4 * g);
-      lin<SPL, 4, 1>(L.A0, LDW, ain, &ah, lane);
-      ah = f4_relu(ah);
-      f4 a[4];
-#pragma unroll
-      for (int M = 0; M < 4; ++M) a[M] = ld4(L.bA2 + 16 * M + 4 * g);
-      lin<SPL, 1, 4>(L.A2, VA_LD8, &ah, a, lane);
+        for (int M = 0; M < 4; ++M) ain[M] = k[M] - qp[M] + pos[M];
+        f4 ah = ld4(L.bA0 + 4 * g);
+        lin<SPL, 4, 1>(L.A0, LDW, ain, &ah, lane);
+        ah = f4_relu(ah);
+        lin<SPL, 1, 4>(L.A2, VA_LD8, &ah, a, lane);
+      }
       if (mk == 0.0f) {
 #pragma unroll
         for (int M = 0; M < 4; ++M) a[M] = f4_splat(-1e9f);  // masked_fill (:83)
@@ -444,26 +514,96 @@ k_ff(const float* __restrict__ norm_w, const float* __restrict__ norm_b, gpn_lin
   __syncthreads();
   const int j = lane & 15, g = lane >> 4;
   const long long ntiles = (N + 15) >> 4;
-  for (long long tile = (long long)blockIdx.x * (FF_TPB / 64) + wave; tile < ntiles;
-       tile += (long long)gridDim.x * (FF_TPB / 64)) {
-    const long long n = tile * 16 + j;
-    const bool valid = n < N;
-    const long long nc = valid ? n : N - 1;
-    f4 x[4], xn[4], h[16], y[4];
+  if constexpr (SPL) {
+    // FF_NTL point tiles per wave; the hidden layer is produced and consumed in four 64-wide
+    // chunks, so the 256 hidden values of a point never exist at once
+    constexpr int NTL = FF_NTL;
+    const bf8* w1p = reinterpret_cast<const bf8*>(W1) + lane;
+    const bf8* w2p = reinterpret_cast<const bf8*>(W2) + lane;
+    const long long ngroups = (ntiles + NTL - 1) / NTL;
+    const long long stride = (long long)gridDim.x * (FF_TPB / 64);
+    long long pr = (long long)blockIdx.x * (FF_TPB / 64) + wave;
+    // the input tiles of the next iteration are loaded one iteration ahead
+    f4 xpre[NTL][4];
 #pragma unroll
-    for (int T = 0; T < 4; ++T) x[T] = ld4(x_in + (size_t)nc * C64 + 16 * T + 4 * g);
-    layernorm_T(x, xn, gam, bet, 1e-6f, lane);
+    for (int t = 0; t < NTL; ++t) {
+      const long long np = (pr * NTL + t) * 16 + j, npc = np < N ? np : N - 1;
 #pragma unroll
-    for (int M = 0; M < 16; ++M) h[M] = ld4(b1 + 16 * M + 4 * g);
-    lin<SPL, 4, 16>(W1, LDW, xn, h, lane);
+      for (int T = 0; T < 4; ++T) xpre[t][T] = ld4(x_in + (size_t)npc * C64 + 16 * T + 4 * g);
+    }
+    for (; pr < ngroups; pr += stride) {
+      long long n[NTL];
+      XS xs[NTL][2];
+      f4 y[NTL][4], x[NTL][4];
 #pragma unroll
-    for (int M = 0; M < 16; ++M) h[M] = f4_relu(h[M]);
+      for (int t = 0; t < NTL; ++t) {
+        n[t] = (pr * NTL + t) * 16 + j;
 #pragma unroll
-    for (int M = 0; M < 4; ++M) y[M] = ld4(b2 + 16 * M + 4 * g);
-    lin<SPL, 16, 4>(W2, FF_LD2, h, y, lane);
-    if (valid) {
+        for (int T = 0; T < 4; ++T) x[t][T] = xpre[t][T];
+      }
 #pragma unroll
-      for (int M = 0; M < 4; ++M) st4(x_out + (size_t)n * C64 + 16 * M + 4 * g, y[M] + x[M]);
+      for (int t = 0; t < NTL; ++t) {
+        const long long np = ((pr + stride) * NTL + t) * 16 + j, npc = np < N ? np : N - 1;
+#pragma unroll
+        for (int T = 0; T < 4; ++T) xpre[t][T] = ld4(x_in + (size_t)npc * C64 + 16 * T + 4 * g);
+      }
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) {
+        f4 xn[4];
+        layernorm_T(x[t], xn, gam, bet, 1e-6f, lane);
+        xs[t][0] = split8(xn[0], xn[1]);
+        xs[t][1] = split8(xn[2], xn[3]);
+#pragma unroll
+        for (int M = 0; M < 4; ++M) y[t][M] = ld4(b2 + 16 * M + 4 * g);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        f4 h[NTL][4];
+#pragma unroll
+        for (int t = 0; t < NTL; ++t)
+#pragma unroll
+          for (int M = 0; M < 4; ++M) h[t][M] = ld4(b1 + 64 * c + 16 * M + 4 * g);
+        lin_S2<2, 2, 4, NTL>(w1p + (4 * c * 2) * 128, xs, h);  // rows 64c.., all 64 inputs
+        XS hs[NTL][2];
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+          hs[t][0] = split8(f4_relu(h[t][0]), f4_relu(h[t][1]));
+          hs[t][1] = split8(f4_relu(h[t][2]), f4_relu(h[t][3]));
+        }
+        lin_S2<8, 2, 4, NTL>(w2p + (2 * c) * 128, hs, y);      // all 64 rows, hidden 64c..64c+63
+      }
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) {
+        if (n[t] < N) {
+#pragma unroll
+          for (int M = 0; M < 4; ++M) {
+            st4(x_out + (size_t)n[t] * C64 + 16 * M + 4 * g, y[t][M] + x[t][M]);
+          }
+        }
+      }
+    }
+  } else {
+    for (long long tile = (long long)blockIdx.x * (FF_TPB / 64) + wave; tile < ntiles;
+         tile += (long long)gridDim.x * (FF_TPB / 64)) {
+      const long long n = tile * 16 + j;
+      const bool valid = n < N;
+      const long long nc = valid ? n : N - 1;
+      f4 x[4], xn[4], h[16], y[4];
+#pragma unroll
+      for (int T = 0; T < 4; ++T) x[T] = ld4(x_in + (size_t)nc * C64 + 16 * T + 4 * g);
+      layernorm_T(x, xn, gam, bet, 1e-6f, lane);
+#pragma unroll
+      for (int M = 0; M < 16; ++M) h[M] = ld4(b1 + 16 * M + 4 * g);
+      lin_T<4, 16>(W1, LDW, xn, h, lane);
+#pragma unroll
+      for (int M = 0; M < 16; ++M) h[M] = f4_relu(h[M]);
+#pragma unroll
+      for (int M = 0; M < 4; ++M) y[M] = ld4(b2 + 16 * M + 4 * g);
+      lin_T<16, 4>(W2, FF_LD2, h, y, lane);
+      if (valid) {
+#pragma unroll
+        for (int M = 0; M < 4; ++M) st4(x_out + (size_t)n * C64 + 16 * M + 4 * g, y[M] + x[M]);
+      }
     }
   }
 }
@@ -1046,6 +1186,15 @@ extern "C" int gpn_vis_order(const float* mask, int N, int V, int32_t* perm, voi
   return GPN_OK;
 }
 
+extern "C" int gpn_view_fold(const gpn_view_layer_t* L, float* out, gpn_stream_t stream) {
+  GPN_REQUIRE(L && out, "gpn_view_fold: null pointer");
+  GPN_REQUIRE(L->k.w && L->v.w && L->pos2.w && L->attn0.w, "gpn_view_fold: null weight");
+  hipLaunchKernelGGL(k_view_fold, dim3(gpn_ceil_div(GPN_VIEW_FOLD_FLOATS, 256)), dim3(256), 0,
+                     (hipStream_t)stream, *L, out);
+  GPN_LAUNCH_CHECK("k_view_fold");
+  return GPN_OK;
+}
+
 extern "C" int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const float* feat,
                              const float* ray_diff, const float* mask, const int32_t* perm, int N,
                              int V, float* q_out, float* logits, int logits_ld, float* stats,
@@ -1067,20 +1216,26 @@ extern "C" int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const
   GPN_REQUIRE(!stats || (stats_ld >= 2 * C64 && stats_ld % 4 == 0),
               "gpn_view_attn: stats_ld must be a multiple of 4 and >= %d (got %d)", 2 * C64, stats_ld);
   const bool spl = gpn_precision() == GPN_PREC_BF16X3;
+  const bool fold = spl && L->folded != nullptr;
   const size_t lds = sizeof(float) * view_lds_floats(spl);
-  int rc = set_lds_limit(spl ? reinterpret_cast<const void*>(k_view_attn<true>)
-                             : reinterpret_cast<const void*>(k_view_attn<false>), lds);
+  const void* fn = fold ? reinterpret_cast<const void*>(k_view_attn<true, true>)
+                        : spl ? reinterpret_cast<const void*>(k_view_attn<true, false>)
+                              : reinterpret_cast<const void*>(k_view_attn<false, false>);
+  int rc = set_lds_limit(fn, lds);
   if (rc) return rc;
   const int grid = persistent_grid(((long long)N + (VA_TPB / 4) - 1) / (VA_TPB / 4));
   GpnStageTimer timer_k_view_attn_(GPN_ST_VIEW_ATTN, (hipStream_t)stream);
-  if (spl)
-    hipLaunchKernelGGL(k_view_attn<true>, dim3(grid), dim3(VA_TPB), lds, (hipStream_t)stream, *L, q_in,
-                       feat, ray_diff, mask, perm, (long long)N, V, q_out, logits, logits_ld, stats,
-                       stats_ld);
+  const dim3 g3(grid), b3(VA_TPB);
+  hipStream_t st = (hipStream_t)stream;
+  if (fold)
+    hipLaunchKernelGGL((k_view_attn<true, true>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
+                       (long long)N, V, q_out, logits, logits_ld, stats, stats_ld);
+  else if (spl)
+    hipLaunchKernelGGL((k_view_attn<true, false>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
+                       (long long)N, V, q_out, logits, logits_ld, stats, stats_ld);
   else
-    hipLaunchKernelGGL(k_view_attn<false>, dim3(grid), dim3(VA_TPB), lds, (hipStream_t)stream, *L, q_in,
-                       feat, ray_diff, mask, perm, (long long)N, V, q_out, logits, logits_ld, stats,
-                       stats_ld);
+    hipLaunchKernelGGL((k_view_attn<false, false>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
+                       (long long)N, V, q_out, logits, logits_ld, stats, stats_ld);
   GPN_LAUNCH_CHECK("k_view_attn");
   return GPN_OK;
 }

@@ -28,9 +28,9 @@ __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
 
 __device__ __forceinline__ f4 f4_zero() { return (f4){0.f, 0.f, 0.f, 0.f}; }
 __device__ __forceinline__ f4 f4_splat(float v) { return (f4){v, v, v, v}; }
-__device__ __forceinline__ f4 f4_relu(f4 v) {
-  return (f4){fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
-}
+// max(x, 0) as one v_med3_f32 (fmaxf costs a canonicalising v_max first)
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
+__device__ __forceinline__ f4 f4_relu(f4 v) { return (f4){relu1(v.x), relu1(v.y), relu1(v.z), relu1(v.w)}; }
 __device__ __forceinline__ f4 f4_max(f4 a, f4 b) {
   return (f4){fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)};
 }
@@ -276,11 +276,55 @@ __device__ __forceinline__ void lin_Sx(const float* Wf, const XS* xs, f4* y, int
 #pragma unroll
         for (int m = 0; m < MC; ++m) y[M0 + m] = mfma_bf(xs[P].hi, wh[m], y[M0 + m]);
       }
+#ifndef GPN_NO_SB
       __builtin_amdgcn_sched_barrier(0);
+#endif
       if (P + 1 < KP) {
 #pragma unroll
         for (int m = 0; m < MC; ++m) wh[m] = nh[m], wm[m] = nm[m];
       }
+    }
+  }
+}
+
+// Two activation tiles against one weight block: y[t][m] += W[rows 16(M0+m).., pairs P0..P0+NP) . xs[t]
+// for t = 0, 1.  Every weight unit read from LDS feeds two MFMAs (half the LDS traffic per flop of
+// lin_Sx) and the two tiles give the MFMA pipe two independent dependency chains.
+// wp = image base + lane + (M0*KPT + P0)*128 units, KPT = K pairs of the whole image.
+template <int KPT, int NP, int MT, int NTL = 2>
+__device__ __forceinline__ void lin_S2(const bf8* wp, const XS (&xs)[NTL][NP], f4 (&y)[NTL][MT]) {
+  bf8 wh[MT], wm[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    wh[m] = wp[(m * KPT) * 128];
+    wm[m] = wp[(m * KPT) * 128 + 64];
+  }
+#pragma unroll
+  for (int P = 0; P < NP; ++P) {
+    bf8 nh[MT], nm[MT];
+    if (P + 1 < NP) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        nh[m] = wp[(m * KPT + P + 1) * 128];
+        nm[m] = wp[(m * KPT + P + 1) * 128 + 64];
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) y[t][m] = mfma_bf(wm[m], xs[t][P].hi, y[t][m]);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) y[t][m] = mfma_bf(wh[m], xs[t][P].mid, y[t][m]);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) y[t][m] = mfma_bf(wh[m], xs[t][P].hi, y[t][m]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (P + 1 < NP) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) wh[m] = nh[m], wm[m] = nm[m];
     }
   }
 }

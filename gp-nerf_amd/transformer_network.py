@@ -141,6 +141,7 @@ class GNT(nn.Module):
             if p.data_ptr() % 16:
                 raise RuntimeError("GNT parameter %s is not 16-byte aligned" % n)
         W = _lib.GntWeights()
+        folded = []
         W.trans_depth, W.in_feat_ch = self.trans_depth, self.in_feat_ch
         W.rgbfeat0, W.rgbfeat2 = _lin(self.rgbfeat_fc[0]), _lin(self.rgbfeat_fc[2])
         for i in range(self.trans_depth):
@@ -152,6 +153,12 @@ class GNT(nn.Module):
             L.pos0, L.pos2 = _lin(b.attn.pos_fc[0]), _lin(b.attn.pos_fc[2])
             L.attn0, L.attn2 = _lin(b.attn.attn_fc[0]), _lin(b.attn.attn_fc[2])
             L.out = _lin(b.attn.out_fc)
+            # folded weight products for the bf16x3 mode (include/gpnerf_hip.h: gpn_view_fold)
+            fold = torch.empty(_lib.VIEW_FOLD_FLOATS, device=b.attn.q_fc.weight.device)
+            _lib.check(_lib.lib().gpn_view_fold(C.byref(L), _lib.ptr(fold), _lib.stream()),
+                       "gpn_view_fold")
+            L.folded = fold.data_ptr()
+            folded.append(fold)
             b, L = self.view_selftrans[i], W.ray[i]
             L.attn_norm_w, L.attn_norm_b = b.attn_norm.weight.data_ptr(), b.attn_norm.bias.data_ptr()
             L.ff_norm_w, L.ff_norm_b = b.ff_norm.weight.data_ptr(), b.ff_norm.bias.data_ptr()
@@ -163,7 +170,7 @@ class GNT(nn.Module):
         W.norm_w, W.norm_b = self.norm.weight.data_ptr(), self.norm.bias.data_ptr()
         W.rgb_fc = _lin(self.rgb_fc)
         W.sem_adaptor = _lin(self.semantic_adaptor[0])
-        self._wcache = (key, W)
+        self._wcache = (key, W, folded)  # `folded` keeps the derived weight tensors alive
         return W
 
     def _workspace(self, R, S, V, dev):

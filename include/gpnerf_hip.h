@@ -116,6 +116,9 @@ typedef struct {                 /* Transformer2D + Attention2D, transformer_net
   gpn_linear_t pos0, pos2;       /* [C/8,4], [C,C/8] */
   gpn_linear_t attn0, attn2;     /* [C/8,C], [C,C/8] */
   gpn_linear_t out;              /* [C,C] */
+  /* Optional (may be NULL): products of the weights above, made by gpn_view_fold.  Used in
+   * GPN_PREC_BF16X3 mode only; the fp32 mode always follows the reference's operation order. */
+  const float* folded;           /* [GPN_VIEW_FOLD_FLOATS] */
 } gpn_view_layer_t;
 
 typedef struct {                 /* Transformer + Attention('qk'), transformer_network.py:130-218 */
@@ -161,6 +164,16 @@ int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const float* fea
                   const float* ray_diff, const float* mask, const int32_t* perm, int N, int V,
                   float* q_out, float* logits, int logits_ld, float* stats, int stats_ld,
                   gpn_stream_t stream);
+
+/* No counterpart in the reference (weight preprocessing for gpn_view_attn, once per model): folds the
+ * linear chains of Attention2D that have no nonlinearity in between,
+ *   v = v_fc(k_fc(f))                          -> (Wv Wk) f
+ *   attn_fc[0](k - q + pos_fc[2](h) + b_pos2)  -> (A0 Wk) f + (A0 P2) h + (A0 b_pos2 + b_attn0) - A0 q
+ * so that per (point, view) the k product and two fp32->bf16 operand splits disappear.  Products are
+ * accumulated in fp64 and rounded to fp32 once.  out: GPN_VIEW_FOLD_FLOATS floats =
+ * [Wv Wk (C x C) | (A0 Wk | A0 P2 | 0) (16 x 96, rows >= C/8 zero) | A0 b_pos2 + b_attn0 (16)]. */
+#define GPN_VIEW_FOLD_FLOATS (64 * 64 + 16 * 96 + 16)
+int gpn_view_fold(const gpn_view_layer_t* L, float* out, gpn_stream_t stream);
 
 /* No counterpart in the reference (scheduling aid for gpn_view_attn): perm [N] = the points sorted by
  * their set of visible views, so that 16-point tiles are homogeneous and whole (tile, view) pairs

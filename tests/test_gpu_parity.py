@@ -284,6 +284,15 @@ def test_gnt_stages(dev, net, prec, S):
                                    _lib.ptr(mk), None, N, V, _lib.ptr(qo), _lib.ptr(lg), 64,
                                    _lib.ptr(stt), 128, st), "view")
         errs["view_attn%d" % l] = rel(qo, rec["q_view_attn"][l].reshape(N, 64))
+        if l == 0:  # the same layer without the folded weight products (reference operation order)
+            plain = type(W.view[l])()
+            C.memmove(C.byref(plain), C.byref(W.view[l]), C.sizeof(plain))
+            plain.folded = None
+            qo_p = e(N, 64)
+            _lib.check(L.gpn_view_attn(C.byref(plain), _lib.ptr(q_in), _lib.ptr(feat_ref), _lib.ptr(rd),
+                                       _lib.ptr(mk), None, N, V, _lib.ptr(qo_p), None, 64, None, 128, st),
+                       "view-unfolded")
+            errs["view_attn_unfolded"] = rel(qo_p, rec["q_view_attn"][l].reshape(N, 64))
         # same launch in visibility-sorted order: bit-identical outputs
         perm = torch.empty(N, dtype=torch.int32, device=dev)
         scr = torch.empty(L.gpn_vis_order_scratch_bytes(), dtype=torch.uint8, device=dev)

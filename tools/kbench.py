@@ -31,3 +31,4 @@ for N in (128, 32768, 131072, 262144):
     x = torch.randn(R, S, 64, device=dev); xo = torch.empty_like(x); ab = torch.empty(R, S, 4, device=dev)
     t_ra = timeit(lambda: L.gpn_ray_attn(C.byref(W.ray[0]), _lib.ptr(x), R, S, _lib.ptr(xo), _lib.ptr(ab), 4, None, st))
     print("N=%7d  ff %8.1f us  view_attn(dense,V=10) %8.1f us  qpos %8.1f us  ray_attn(S=64,R=%d) %8.1f us" % (N, t_ff, t_va, t_qp, R, t_ra), flush=True)
+

@@ -36,6 +36,7 @@
 extern __shared__ __attribute__((aligned(16))) float smem[];
 
 
+
 static int set_lds_limit(const void* fn, size_t bytes) {
   if (bytes <= 64 * 1024) return GPN_OK;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -101,24 +102,39 @@ k_rgbfeat(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ rgb_feat
   __syncthreads();
   const int j = lane & 15, g = lane >> 4;
   const long long ntiles = (N + 15) >> 4;
-  for (long long tile = (long long)blockIdx.x * (RF_TPB / 64) + wave; tile < ntiles;
-       tile += (long long)gridDim.x * (RF_TPB / 64)) {
+  const long long tstride = (long long)gridDim.x * (RF_TPB / 64);
+  // input row of (point, view), zero-padded to 48 channels; rows are 35 floats (not 16-byte aligned)
+  auto load_row = [&](long long n_, int v_, f4* x_) {
+    const float* row = rgb_feat + ((size_t)n_ * V + v_) * in_ch;
+#pragma unroll
+    for (int T = 0; T < 3; ++T)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 16 * T + 4 * g + r;
+        x_[T][r] = c < in_ch ? row[c] : 0.0f;
+      }
+  };
+  long long tile = (long long)blockIdx.x * (RF_TPB / 64) + wave;
+  if (tile >= ntiles) return;
+  f4 xpre[3];  // the next (tile, view) row is loaded one iteration ahead
+  {
+    const long long n0 = tile * 16 + j;
+    load_row(n0 < N ? n0 : N - 1, 0, xpre);
+  }
+  for (; tile < ntiles; tile += tstride) {
     const long long n = tile * 16 + j;
     const bool valid = n < N;
     const long long nc = valid ? n : N - 1;
+    const long long nn = (tile + tstride) * 16 + j, nnc = nn < N ? nn : N - 1;
     f4 qmax[4];
 #pragma unroll
     for (int M = 0; M < 4; ++M) qmax[M] = f4_splat(-INFINITY);
     for (int v = 0; v < V; ++v) {
-      const float* row = rgb_feat + ((size_t)nc * V + v) * in_ch;
       f4 x[3];
 #pragma unroll
-      for (int T = 0; T < 3; ++T)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int c = 16 * T + 4 * g + r;
-          x[T][r] = c < in_ch ? row[c] : 0.0f;
-        }
+      for (int T = 0; T < 3; ++T) x[T] = xpre[T];
+      if (v + 1 < V) load_row(nc, v + 1, xpre);
+      else load_row(nnc, 0, xpre);
       f4 h[4], y[4];
 #pragma unroll
       for (int M = 0; M < 4; ++M) h[M] = ld4(b0 + 16 * M + 4 * g);
@@ -150,10 +166,16 @@ k_rgbfeat(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ rgb_feat
 #define VIS_BINS 4096
 #define VIS_CHUNK 2048  // points per block
 
-__device__ __forceinline__ unsigned vis_bin(const float* __restrict__ mrow, int V) {
+__device__ __forceinline__ unsigned vis_bits(const float* __restrict__ mrow, int V) {
   unsigned key = 0;
   for (int v = 0; v < V; ++v) key |= (mrow[v] != 0.0f ? 1u : 0u) << v;
+  return key;
+}
+__device__ __forceinline__ unsigned vis_bin_of(unsigned key, int V) {
   return V <= 12 ? key : ((key * 2654435761u) >> 20);
+}
+__device__ __forceinline__ unsigned vis_bin(const float* __restrict__ mrow, int V) {
+  return vis_bin_of(vis_bits(mrow, V), V);
 }
 
 __global__ void __launch_bounds__(256)
@@ -207,19 +229,20 @@ k_vis_scan(const int* __restrict__ hist, int* __restrict__ cursor, int V) {
 
 __global__ void __launch_bounds__(256)
 k_vis_scatter(const float* __restrict__ mask, int N, int V, int* __restrict__ cursor,
-              int* __restrict__ perm) {
+              int* __restrict__ perm) {  // perm [2N]: point of every slot, then its visibility bits
   __shared__ int lh[VIS_BINS];
   for (int b = threadIdx.x; b < VIS_BINS; b += 256) lh[b] = 0;
   __syncthreads();
   const int n0 = blockIdx.x * VIS_CHUNK;
   int rank[VIS_CHUNK / 256];
-  unsigned bin[VIS_CHUNK / 256];
+  unsigned bin[VIS_CHUNK / 256], bits[VIS_CHUNK / 256];
 #pragma unroll
   for (int k = 0; k < VIS_CHUNK / 256; ++k) {
     const int i = threadIdx.x + 256 * k;
     rank[k] = -1;
     if (n0 + i < N) {
-      bin[k] = vis_bin(mask + (size_t)(n0 + i) * V, V);
+      bits[k] = vis_bits(mask + (size_t)(n0 + i) * V, V);
+      bin[k] = vis_bin_of(bits[k], V);
       rank[k] = atomicAdd(&lh[bin[k]], 1);
     }
   }
@@ -229,7 +252,11 @@ k_vis_scatter(const float* __restrict__ mask, int N, int V, int* __restrict__ cu
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < VIS_CHUNK / 256; ++k)
-    if (rank[k] >= 0) perm[lh[bin[k]] + rank[k]] = n0 + threadIdx.x + 256 * k;
+    if (rank[k] >= 0) {
+      const int slot = lh[bin[k]] + rank[k];
+      perm[slot] = n0 + threadIdx.x + 256 * k;
+      perm[N + slot] = (int)bits[k];
+    }
 }
 
 // ------------------------------------------------------------------------------------ view attention
@@ -334,19 +361,72 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
   const int j = lane & 15, g = lane >> 4;
   const float p0w = L.P0[j * 4 + g];  // A operand of the 4 -> 8 layer: W[i = j][k = g]
   const long long ntiles = (N + 15) >> 4;
-  for (long long tile = (long long)blockIdx.x * (VA_TPB / 64) + wave; tile < ntiles;
-       tile += (long long)gridDim.x * (VA_TPB / 64)) {
-    // slot -> point: identity, or the visibility-sorted order of gpn_vis_order (points with the
-    // same set of visible views share tiles, which makes the dead-view skip below effective)
-    const long long slot = tile * 16 + j;
-    const bool valid = slot < N;
-    const long long sc = valid ? slot : N - 1;
-    const long long n = perm != nullptr ? (long long)perm[sc] : sc;
-    const long long nc = n;
+  const long long tstride = (long long)gridDim.x * (VA_TPB / 64);
+  const unsigned all_views = V >= 32 ? 0xffffffffu : ((1u << V) - 1u);
+  const int* vbits = perm != nullptr ? perm + N : nullptr;  // gpn_vis_order: bit masks in slot order
 
-    f4 xq[4], qp[4];
+  // The tile loop is software-pipelined over tiles: while a tile computes, the point index and
+  // visibility bits (top of the tile), the q rows (before the view loop) and the first live view
+  // (in the last view iteration) of the wave's NEXT tile are already being fetched, so a tile
+  // starts without a chain of dependent global loads.
+  // slot -> point: identity, or the visibility-sorted order of gpn_vis_order (points with the same
+  // set of visible views share tiles, which makes the dead-view skip below effective).
+  auto point_of = [&](long long tile_, int& n_, unsigned& vis_) {
+    const long long slot = tile_ * 16 + j, sc = slot < N ? slot : N - 1;
+    if (perm != nullptr) {
+      n_ = perm[sc];
+      vis_ = (unsigned)vbits[sc];
+    } else {
+      n_ = (int)sc;
+      unsigned b = 0;  // lane (j, g) reads views g, g+4, ... of point j; all loads independent
 #pragma unroll
-    for (int T = 0; T < 4; ++T) xq[T] = ld4(q_in + (size_t)nc * C64 + 16 * T + 4 * g);
+      for (int k = 0; k < GPN_MAX_VIEWS / 4; ++k) {
+        const int v = 4 * k + g, vc = v < V ? v : V - 1;
+        const float m = mask[(size_t)sc * V + vc];
+        b |= (v < V && m != 0.0f ? 1u : 0u) << (v & 31);
+      }
+      b |= __shfl_xor(b, 16);
+      b |= __shfl_xor(b, 32);
+      vis_ = b;
+    }
+  };
+  // live views of a tile (wave-uniform): visible for some point, or needed by a point that has no
+  // visible view at all (its softmax is uniform over all V views)
+  auto live_of = [&](unsigned vis_) {
+    unsigned m = vis_ != 0 ? vis_ : all_views;
+    m |= __shfl_xor(m, 1);
+    m |= __shfl_xor(m, 2);
+    m |= __shfl_xor(m, 4);
+    m |= __shfl_xor(m, 8);
+    return (unsigned)__builtin_amdgcn_readfirstlane(m);
+  };
+
+  long long tile = (long long)blockIdx.x * (VA_TPB / 64) + wave;
+  if (tile >= ntiles) return;
+  int n;  // N fits an int (C-ABI)
+  unsigned vis;
+  point_of(tile, n, vis);
+  unsigned live = live_of(vis);
+  f4 xq[4], fcur[4];
+  float rdcur;
+#pragma unroll
+  for (int T = 0; T < 4; ++T) xq[T] = ld4(q_in + (size_t)n * C64 + 16 * T + 4 * g);
+  {
+    const int v0 = __builtin_ctz(live);
+#pragma unroll
+    for (int T = 0; T < 4; ++T) fcur[T] = ld4(feat + ((size_t)n * V + v0) * C64 + 16 * T + 4 * g);
+    rdcur = ray_diff[((size_t)n * V + v0) * 4 + g];
+  }
+
+  for (;;) {
+    const bool valid = tile * 16 + j < N;
+    const long long tile_next = tile + tstride;
+    const bool has_next = tile_next < ntiles;  // wave-uniform
+    int n_next = n;
+    unsigned vis_next = vis;
+    if (has_next) point_of(tile_next, n_next, vis_next);
+
+    f4 qp[4];
     {
       f4 qn[4];
       layernorm_T(xq, qn, L.gam, L.bet, 1e-6f, lane);
@@ -360,6 +440,14 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
       lin<SPL, 4, 1>(L.A0, LDW, qp, &t, lane);
       aq = ld4(L.c0 + 4 * g) - t;
     }
+    // next tile's q rows (the residual input of THIS tile is re-read at the end instead of being
+    // held in 16 registers through the view loop)
+    const unsigned live_next = has_next ? live_of(vis_next) : 0u;
+    if constexpr (FOLD) {  // (the other variants have no registers to spare here: they fetch it after the loop)
+#pragma unroll
+      for (int T = 0; T < 4; ++T) xq[T] = ld4(q_in + (size_t)n_next * C64 + 16 * T + 4 * g);
+    }
+
     f4 mrun[4], lrun[4], acc[4];
 #pragma unroll
     for (int M = 0; M < 4; ++M) {
@@ -369,57 +457,39 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
     }
     // A masked view contributes exp(-1e9 - max) == 0 exactly as soon as the point has one visible
     // view, so a (tile, view) whose 16 points are all masked-but-visible-elsewhere is skipped whole.
-    unsigned vis = 0;  // this point's visible views
-    for (int v = 0; v < V; ++v) vis |= (mask[(size_t)nc * V + v] != 0.0f ? 1u : 0u) << v;
-    // live views of the tile (wave-uniform): visible for some point, or needed by a point that has
-    // no visible view at all (its softmax is uniform over all V views)
-    unsigned live = 0;
-    {
-      const bool none = vis == 0;
-      for (int v = 0; v < V; ++v)
-        if (__any(none || ((vis >> v) & 1u))) live |= 1u << v;
-    }
-    live = __builtin_amdgcn_readfirstlane(live);
-    const float* frow = feat + (size_t)nc * V * C64 + 4 * g;
-    const float* rdrow = ray_diff + (size_t)nc * V * 4 + g;
-    f4 fcur[4];
-    float rdcur;
-    {
-      const int v0 = live ? __builtin_ctz(live) : 0;
-#pragma unroll
-      for (int T = 0; T < 4; ++T) fcur[T] = ld4(frow + (size_t)v0 * C64 + 16 * T);
-      rdcur = rdrow[v0 * 4];
-    }
+    const int v0_next = live_next ? __builtin_ctz(live_next) : 0;
 
     while (live) {
       const int v = __builtin_ctz(live);
       live &= live - 1;
-      f4 fnext[4];  // prefetch the next LIVE view while this one computes
-      const int vn = live ? __builtin_ctz(live) : v;
-#pragma unroll
-      for (int T = 0; T < 4; ++T) fnext[T] = ld4(frow + (size_t)vn * C64 + 16 * T);
+      // The next LIVE view (in the last iteration: the first live view of the next tile) is fetched
+      // into the same registers as soon as this view's features have been consumed.
+      const size_t pair_next = live ? (size_t)n * V + __builtin_ctz(live) : (size_t)n_next * V + v0_next;
+      const float* fsrc = feat + pair_next * C64 + 4 * g;
+      const float* rsrc = ray_diff + pair_next * 4 + g;
       const float rd = rdcur;
-      rdcur = rdrow[vn * 4];
+      rdcur = *rsrc;
       const float mk = (vis >> v) & 1u ? 1.0f : 0.0f;
 
-      f4 val[4], pos[4], a[4];
+      f4 vp[4], a[4];  // vp = v + pos (the value that is attended over)
 #pragma unroll
       for (int M = 0; M < 4; ++M) {
-        val[M] = f4_zero();
-        pos[M] = ld4(L.bP2 + 16 * M + 4 * g);
+        vp[M] = ld4(L.bP2 + 16 * M + 4 * g);
         a[M] = ld4(L.bA2 + 16 * M + 4 * g);
       }
       // pos hidden layer: 4 -> 8 (ReLU), one fp32 MFMA
       f4 ph = f4_relu(mfma16(p0w, rd, ld4(L.bP0 + 4 * g)));
       if constexpr (FOLD) {
-        // v = (Wv Wk) f ; pos = P2 h + b ; attn hidden = (A0 Wk) f + (A0 P2) h + aq : every product
+        // v + pos = (Wv Wk) f + P2 h + b ; attn hidden = (A0 Wk) f + (A0 P2) h + aq : every product
         // reads the split of f and h made once here
         XS xs[3];
         xs[0] = split8(fcur[0], fcur[1]);
         xs[1] = split8(fcur[2], fcur[3]);
         xs[2] = split8(ph, f4_zero());
-        lin_Sx<4, 4>(L.Wv, xs, val, lane);
-        lin_Sx<1, 4>(L.P2, xs + 2, pos, lane);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) fcur[T] = ld4(fsrc + 16 * T);
+        lin_Sx<4, 4>(L.Wv, xs, vp, lane);
+        lin_Sx<1, 4>(L.P2, xs + 2, vp, lane);
         f4 ah = aq;
         lin_Sx<6, 1>(L.AF, xs, &ah, lane);
         ah = f4_relu(ah);
@@ -429,12 +499,21 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
 #pragma unroll
         for (int M = 0; M < 4; ++M) k[M] = f4_zero();
         lin<SPL, 4, 4>(L.Wk, LDW, fcur, k, lane);   // k = k_fc(feat)
-        lin<SPL, 4, 4>(L.Wv, LDW, k, val, lane);    // v = v_fc(k)   (reference quirk, :77)
+#pragma unroll
+        for (int T = 0; T < 4; ++T) fcur[T] = ld4(fsrc + 16 * T);
+        f4 pos[4];
+#pragma unroll
+        for (int M = 0; M < 4; ++M) pos[M] = vp[M];
         lin<SPL, 1, 4>(L.P2, VA_LD8, &ph, pos, lane);  // pos = pos_fc(ray_diff): 4 -> 8 -> 64
         // attn = attn_fc(k - q + pos): 64 -> 8 (ReLU) -> 64
         f4 ain[4];
 #pragma unroll
         for (int M = 0; M < 4; ++M) ain[M] = k[M] - qp[M] + pos[M];
+#pragma unroll
+        for (int M = 0; M < 4; ++M) vp[M] = f4_zero();
+        lin<SPL, 4, 4>(L.Wv, LDW, k, vp, lane);     // v = v_fc(k)   (reference quirk, :77)
+#pragma unroll
+        for (int M = 0; M < 4; ++M) vp[M] = vp[M] + pos[M];
         f4 ah = ld4(L.bA0 + 4 * g);
         lin<SPL, 4, 1>(L.A0, LDW, ain, &ah, lane);
         ah = f4_relu(ah);
@@ -449,22 +528,28 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
 #pragma unroll
         for (int M = 0; M < 4; ++M) st4(lo + 16 * M, a[M]);
       }
-      // online softmax over views, per channel (:84-87)
+      // online softmax over views, per channel (:84-87).  One of the two rescale factors is always
+      // exp(0) = 1, so a single exponential of -|a - max| serves both.
 #pragma unroll
       for (int M = 0; M < 4; ++M)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float mn = fmaxf(mrun[M][r], a[M][r]);
-          const float alpha = __expf(mrun[M][r] - mn);
-          const float p = __expf(a[M][r] - mn);
+          const float d = a[M][r] - mrun[M][r];
+          const float e = __expf(-fabsf(d));
+          const bool up = d > 0.0f;  // new maximum
+          const float alpha = up ? e : 1.0f, p = up ? 1.0f : e;
           lrun[M][r] = lrun[M][r] * alpha + p;
-          acc[M][r] = acc[M][r] * alpha + (val[M][r] + pos[M][r]) * p;
-          mrun[M][r] = mn;
+          acc[M][r] = acc[M][r] * alpha + vp[M][r] * p;
+          mrun[M][r] = up ? a[M][r] : mrun[M][r];
         }
-#pragma unroll
-      for (int T = 0; T < 4; ++T) fcur[T] = fnext[T];
     }
-    f4 xs[4], y[4], rl[4];
+    f4 xr[4], xs[4], y[4], rl[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) xr[T] = ld4(q_in + (size_t)n * C64 + 16 * T + 4 * g);  // residual input
+    if constexpr (!FOLD) {
+#pragma unroll
+      for (int T = 0; T < 4; ++T) xq[T] = ld4(q_in + (size_t)n_next * C64 + 16 * T + 4 * g);
+    }
 #pragma unroll
     for (int M = 0; M < 4; ++M) {
 #pragma unroll
@@ -475,7 +560,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
     lin<SPL, 4, 4>(L.Wo, LDW, xs, y, lane);
     if (valid) {
 #pragma unroll
-      for (int M = 0; M < 4; ++M) st4(q_out + (size_t)n * C64 + 16 * M + 4 * g, y[M] + xq[M]);
+      for (int M = 0; M < 4; ++M) st4(q_out + (size_t)n * C64 + 16 * M + 4 * g, y[M] + xr[M]);
       if (stats != nullptr) {
 #pragma unroll
         for (int M = 0; M < 4; ++M) {
@@ -484,6 +569,11 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
         }
       }
     }
+    if (!has_next) break;
+    tile = tile_next;
+    n = n_next;
+    vis = vis_next;
+    live = live_next;
   }
 }
 
@@ -631,16 +721,25 @@ k_qpos(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ q_in,
   __syncthreads();
   const int j = lane & 15, g = lane >> 4;
   const long long ntiles = (N + 15) >> 4;
-  for (long long tile = (long long)blockIdx.x * (QP_TPB / 64) + wave; tile < ntiles;
-       tile += (long long)gridDim.x * (QP_TPB / 64)) {
+  const long long tstride = (long long)gridDim.x * (QP_TPB / 64);
+  auto load_x = [&](long long tile_, f4* x_) {
+    const long long n_ = tile_ * 16 + j, c_ = n_ < N ? n_ : N - 1;
+#pragma unroll
+    for (int T = 0; T < 4; ++T) x_[T] = ld4(q_in + (size_t)c_ * C64 + 16 * T + 4 * g);
+#pragma unroll
+    for (int T = 0; T < 8; ++T) x_[4 + T] = ld4(emb + (size_t)c_ * GPN_EMB + 16 * T + 4 * g);
+  };
+  long long tile = (long long)blockIdx.x * (QP_TPB / 64) + wave;
+  if (tile >= ntiles) return;
+  f4 xpre[12];  // the next tile's inputs are loaded one iteration ahead
+  load_x(tile, xpre);
+  for (; tile < ntiles; tile += tstride) {
     const long long n = tile * 16 + j;
     const bool valid = n < N;
-    const long long nc = valid ? n : N - 1;
     f4 x[12], h[4], y[4];
 #pragma unroll
-    for (int T = 0; T < 4; ++T) x[T] = ld4(q_in + (size_t)nc * C64 + 16 * T + 4 * g);
-#pragma unroll
-    for (int T = 0; T < 8; ++T) x[4 + T] = ld4(emb + (size_t)nc * GPN_EMB + 16 * T + 4 * g);
+    for (int T = 0; T < 12; ++T) x[T] = xpre[T];
+    load_x(tile + tstride, xpre);
 #pragma unroll
     for (int M = 0; M < 4; ++M) h[M] = ld4(b0 + 16 * M + 4 * g);
     lin<SPL, 12, 4>(W0, QP_LD0, x, h, lane);
@@ -1424,7 +1523,7 @@ static GntWs gnt_ws_layout(int R, int S, int V, int depth) {
   w.abar = o, o += align_up(N * depth * 4 * f);           // [R,S,depth,4]
   w.weights = o, o += align_up(N * f);
   w.pre = o, o += align_up((size_t)R * GPN_SEM * f);
-  w.perm = o, o += align_up(N * sizeof(int));
+  w.perm = o, o += align_up(2 * N * sizeof(int));  // points in slot order | their visibility bits
   w.vis_scratch = o, o += align_up(2 * VIS_BINS * sizeof(int));
   w.total = o;
   return w;

@@ -152,7 +152,7 @@ int gpn_rgbfeat(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* r
 
 /* Attention part of Transformer2D (attn_norm, Attention2D, residual), transformer_network.py:74-88
  * and :107-112.  q_in [N,C], feat [N,V,C], ray_diff [N,V,4], mask [N,V] -> q_out [N,C];
- * perm [N] (or NULL): processing order from gpn_vis_order.
+ * perm [2N] (or NULL): processing order + visibility bits from gpn_vis_order.
  * logits: C pre-softmax attention values per VISIBLE (point, view) pair (mask != 0; entries of
  * masked pairs are left unwritten: their softmax weight is exactly 0, or exactly 1/V when the
  * point has no visible view at all), the row of pair (n, v) starting at logits[(n*V+v)*logits_ld];
@@ -175,10 +175,12 @@ int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const float* fea
 #define GPN_VIEW_FOLD_FLOATS (64 * 64 + 16 * 96 + 16)
 int gpn_view_fold(const gpn_view_layer_t* L, float* out, gpn_stream_t stream);
 
-/* No counterpart in the reference (scheduling aid for gpn_view_attn): perm [N] = the points sorted by
- * their set of visible views, so that 16-point tiles are homogeneous and whole (tile, view) pairs
- * can be skipped exactly.  perm == NULL in gpn_view_attn means identity; results are bit-identical
- * either way.  scratch: gpn_vis_order_scratch_bytes() bytes of device memory. */
+/* No counterpart in the reference (scheduling aid for gpn_view_attn): perm [2N] = the points sorted by
+ * their set of visible views (first N entries), so that 16-point tiles are homogeneous and whole
+ * (tile, view) pairs can be skipped exactly, followed by the visibility bit mask (bit v = mask[n][v]
+ * != 0) of the point in each slot (last N entries).  perm == NULL in gpn_view_attn means identity
+ * order with the bits read from `mask`; results are bit-identical either way.
+ * scratch: gpn_vis_order_scratch_bytes() bytes of device memory. */
 size_t gpn_vis_order_scratch_bytes(void);
 int gpn_vis_order(const float* mask, int N, int V, int32_t* perm, void* scratch, gpn_stream_t stream);
 

@@ -294,11 +294,13 @@ def test_gnt_stages(dev, net, prec, S):
                        "view-unfolded")
             errs["view_attn_unfolded"] = rel(qo_p, rec["q_view_attn"][l].reshape(N, 64))
         # same launch in visibility-sorted order: bit-identical outputs
-        perm = torch.empty(N, dtype=torch.int32, device=dev)
+        perm2 = torch.empty(2 * N, dtype=torch.int32, device=dev)
         scr = torch.empty(L.gpn_vis_order_scratch_bytes(), dtype=torch.uint8, device=dev)
-        _lib.check(L.gpn_vis_order(_lib.ptr(mk), N, V, _lib.ptr(perm), _lib.ptr(scr), st), "vis_order")
+        _lib.check(L.gpn_vis_order(_lib.ptr(mk), N, V, _lib.ptr(perm2), _lib.ptr(scr), st), "vis_order")
+        perm, pbits = perm2[:N], perm2[N:]
         assert torch.equal(torch.sort(perm.long())[0].cpu(), torch.arange(N)), "perm is not a permutation"
         key = ((mk.reshape(N, V) != 0).long() << torch.arange(V, device=dev)).sum(-1)[perm.long()]
+        assert torch.equal(pbits.long(), key), "visibility bits do not match the mask"
         cost = torch.where(key == 0, torch.full_like(key, V), (mk.reshape(N, V) != 0).sum(-1)[perm.long()])
         assert bool((cost[1:] <= cost[:-1]).all()), "perm is not ordered by decreasing cost class"
         runs = int((key[1:] != key[:-1]).sum()) + 1
@@ -306,7 +308,7 @@ def test_gnt_stages(dev, net, prec, S):
         qo2, lg2, stt2 = e(N, 64), torch.zeros_like(lg), e(N, 2, 64)
         lg.masked_fill_(mk.reshape(N, V, 1) == 0, 0.0)  # unwritten (masked) entries -> 0 on both sides
         _lib.check(L.gpn_view_attn(C.byref(W.view[l]), _lib.ptr(q_in), _lib.ptr(feat_ref), _lib.ptr(rd),
-                                   _lib.ptr(mk), _lib.ptr(perm), N, V, _lib.ptr(qo2), _lib.ptr(lg2), 64,
+                                   _lib.ptr(mk), _lib.ptr(perm2), N, V, _lib.ptr(qo2), _lib.ptr(lg2), 64,
                                    _lib.ptr(stt2), 128, st), "view-perm")
         lg2.masked_fill_(mk.reshape(N, V, 1) == 0, 0.0)
         assert torch.equal(qo, qo2) and torch.equal(stt, stt2) and torch.equal(lg, lg2), \

@@ -32,3 +32,12 @@ for N in (128, 32768, 131072, 262144):
     t_ra = timeit(lambda: L.gpn_ray_attn(C.byref(W.ray[0]), _lib.ptr(x), R, S, _lib.ptr(xo), _lib.ptr(ab), 4, None, st))
     print("N=%7d  ff %8.1f us  view_attn(dense,V=10) %8.1f us  qpos %8.1f us  ray_attn(S=64,R=%d) %8.1f us" % (N, t_ff, t_va, t_qp, R, t_ra), flush=True)
 
+
+# optional: in-kernel cycle stamps of an instrumented build (tools only; -DGPN_STAMP)
+import ctypes
+h = ctypes.CDLL(_lib.LIB_PATH)
+if hasattr(h, "gpn_debug_stamps"):
+    buf = (ctypes.c_ulonglong * 64)()
+    h.gpn_debug_stamps(buf)
+    st_ = list(buf)[:24]
+    print("stamps:", [st_[i] - st_[0] for i in range(24)])

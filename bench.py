@@ -13,9 +13,16 @@ inputs resident in HBM, outputs left on the device.  With N>1 every rank renders
 chunk from its row shard of the image (weak scaling) and the rgb/depth/feats_out tiles of both
 levels are all-gathered over RCCL inside the timed region.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_view_attn, fp32 MFMA):
-algorithmic flops per launch / mean launch duration measured with HIP events inside the timed
-steps.  `cpu_baseline` is the CPU oracle (a port of the reference path) on a bounded ray sample.
+Arithmetic: the default mode is "bf16x3" -- every fp32 product of the GNT linear layers is evaluated
+as three bf16 MFMAs on split operands with fp32 accumulation (include/gpnerf_hip.h); it meets the
+same 1e-4 parity bar as the exact-fp32 mode (tests/test_gpu_parity.py runs both).  The exact mode
+(fp32 MFMA, reference operation order) is timed too and reported under "fp32_exact".
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_view_attn): algorithmic
+flops per launch (the reference algorithm's GEMM flops, whether or not the kernel
+executes them) / mean launch duration measured with HIP events inside the timed steps, against
+the MFMA peak of the mode.  `cpu_baseline` is the CPU oracle (a port of the reference path) on a
+bounded ray sample.
 """
 import argparse
 import json
@@ -31,7 +38,9 @@ sys.path.insert(0, ROOT)
 
 CHUNK = int(os.environ.get("GPN_BENCH_CHUNK", "4096"))  # rays per step per GPU (4096: the north-star chunk)
 N_SAMPLES, N_IMPORTANCE, VIEWS = 48, 16, 10
-FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
+FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
+BF16_MATRIX_PEAK_TFLOPS = 2500.0  # dense; a bf16x3 product costs three MFMA flops per algorithmic flop
+HBM_PEAK_GBPS = 8000.0
 
 
 def view_attn_flops_per_point(V):
@@ -40,6 +49,47 @@ def view_attn_flops_per_point(V):
     per sample q_fc + out_fc (2 x 8192).  (SURVEY.md 8(d) minus the deep-semantic MAC and the FF,
     which run in other kernels here.)"""
     return V * (2 * 8192 + 1088 + 2048) + 2 * 8192
+
+
+# MFMA flops the kernel executes (MAC = 2; every bf16x3 product counts its three MFMAs).
+# bf16x3 (folded weights): per computed pair (Wv Wk) 8192 + pos_fc[2] 1024 + (A0 Wk | A0 P2) 1152 +
+# attn_fc[2] 1024 = 11392, x3; + fp32 pos_fc[0] 64.  Per point q_fc + out_fc + A0 q = 17408, x3.
+# fp32: the reference order, k 8192 + v 8192 + pos 64 + 1024 + attn 1024 + 1024 per pair, 16384 per point.
+VIEW_EXEC_FLOPS_PER_PAIR = {"bf16x3": 3 * 11392 + 64, "fp32": 19520}
+VIEW_EXEC_FLOPS_PER_POINT = {"bf16x3": 3 * 17408, "fp32": 16384}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 as the
+    gfx950 correction + WRITE_SIZE, separate runs of this same command): profiles/r01_pmc_traffic.json.
+    None if the file is missing."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)[kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def visibility_stats(scene, rb, ret, projector):
+    """Fractions of (sample, view) pairs the view transformer has to compute / that are visible, over
+    the two passes of one step (coarse samples + the fine samples derived from the coarse weights)."""
+    from gp_nerf_amd import render_ray as rr
+    sv = projector.prepare(rb["camera"], rb["src_rgbs"], rb["src_cameras"], scene.featmaps, scene.deep)
+    pts_c, z_c = rr.sample_along_camera_ray(rb["ray_o"], rb["ray_d"], rb["depth_range"], N_SAMPLES,
+                                            inv_uniform=True, det=True)
+    pts_f, _ = rr.sample_fine_pts(True, N_IMPORTANCE, True, N_SAMPLES, rb,
+                                  ret["outputs_coarse"]["weights"], z_c)
+    vis_pairs = comp_pairs = pts = 0
+    for p in (pts_c, pts_f):
+        _, _, mask = projector.compute_fused(p, sv)
+        m = mask.reshape(-1, VIEWS) != 0
+        nvis = m.sum(-1)
+        vis_pairs += int(nvis.sum())
+        comp_pairs += int(torch.where(nvis == 0, torch.full_like(nvis, VIEWS), nvis).sum())
+        pts += m.shape[0]
+    return {"visible_pair_fraction": vis_pairs / (pts * VIEWS),
+            "computed_pair_fraction": comp_pairs / (pts * VIEWS)}
 
 
 def build(dev, seed=1234):
@@ -108,7 +158,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-rays", type=int, default=1536, help="rays of the CPU baseline sample (0: skip)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-stage time table to stderr")
-    ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16x3"),
+    ap.add_argument("--precision", default="bf16x3", choices=("fp32", "bf16x3"),
                     help="arithmetic of the GNT linear layers (see include/gpnerf_hip.h)")
     a = ap.parse_args()
 
@@ -153,30 +203,61 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        ret = step()
-    fence()
-    t0 = time.perf_counter()
-    with _lib.stage_timing(stages=("view_attn",), max_records=32 * a.steps + 64) as tm:
-        for _ in range(a.steps):
-            ret = step()
+    def timed(precision, steps, warmup):
+        """W warm-up steps, then K steps between fences; max over ranks; k_view_attn event-timed."""
+        net.precision = precision
+        for _ in range(warmup):
+            r = step()
         fence()
-        elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t0 = time.perf_counter()
+        with _lib.stage_timing(stages=("view_attn",), max_records=32 * steps + 64) as tm_:
+            for _ in range(steps):
+                r = step()
+            fence()
+            dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return r, dt, tm_
+
+    ret, elapsed, tm = timed(a.precision, a.steps, a.warmup)
 
     # dominant kernel: k_view_attn, 8 launches on N=4096*48 points + 8 on N=4096*64 per step
     launches = tm.launches["view_attn"]
     mean_ms = tm.ms["view_attn"] / max(1, launches)
-    flops_per_launch = view_attn_flops_per_point(VIEWS) * CHUNK * (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) / 2.0
+    pts_per_launch = CHUNK * (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) / 2.0
+    flops_per_launch = view_attn_flops_per_point(VIEWS) * pts_per_launch
     achieved = flops_per_launch / (mean_ms * 1e-3) / 1e12
-    roofline = {"bound": "mfma", "kernel": "k_view_attn", "achieved": achieved,
-                "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
-                "launches": launches, "mean_launch_ms": mean_ms,
+    if a.precision == "bf16x3":
+        peak, peak_note = BF16_MATRIX_PEAK_TFLOPS / 3.0, "dense bf16 MFMA peak / 3 (three bf16 MFMAs per product)"
+    else:
+        peak, peak_note = FP32_MATRIX_PEAK_TFLOPS, "fp32 MFMA peak"
+    vstat = visibility_stats(scene, rb, ret, projector) if rank == 0 else None
+    roofline = {"bound": "mfma", "kernel": "k_view_attn", "achieved": achieved, "peak": peak,
+                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": pmc_traffic("k_view_attn"),
+                "peak_note": peak_note, "launches": launches, "mean_launch_ms": mean_ms,
                 "flops_per_launch": flops_per_launch}
+    if vstat is not None:
+        # what the kernel really executes / moves (dead views skipped, folded weights): see DESIGN.md
+        live = vstat["computed_pair_fraction"]
+        ex_flops = (VIEWS * live * VIEW_EXEC_FLOPS_PER_PAIR[a.precision] +
+                    VIEW_EXEC_FLOPS_PER_POINT[a.precision]) * pts_per_launch
+        alg_bytes = (VIEWS * live * (256 + 16) + VIEWS * vstat["visible_pair_fraction"] * 256 +
+                     256 + 256 + 512 + 8) * pts_per_launch
+        roofline.update({
+            "executed_mfma_tflops": ex_flops / (mean_ms * 1e-3) / 1e12,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "hbm_achieved_GBps": alg_bytes / (mean_ms * 1e-3) / 1e9,
+            "hbm_frac": alg_bytes / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "visibility": vstat})
+
+    if True:  # the other arithmetic mode on the same workload (shorter run; every rank takes part)
+        omode = "fp32" if a.precision == "bf16x3" else "bf16x3"
+        _, dt_o, _ = timed(omode, max(3, a.steps // 2), 2)
+        other = {"precision": omode, "value": world * CHUNK * max(3, a.steps // 2) / dt_o,
+                 "ms_per_step": 1e3 * dt_o / max(3, a.steps // 2)}
+        net.precision = a.precision
 
     stages = None
     if a.breakdown or rank == 0:
@@ -190,25 +271,59 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and a.cpu_rays > 0:
         want, cpu = cpu_baseline(scene, rb, a.cpu_rays)
+        # The 16 importance samples are an inverse-CDF lookup of the coarse weights, and visibility is
+        # a hard in-frustum test: a 1e-7 change of the coarse weights can move a sample across a CDF
+        # bin edge or across the border of a source image (reference behaviour, any two platforms
+        # differ this way).  Rays whose fine depths or visibility masks differ between the GPU run
+        # and the CPU run are counted and left out of the fine-level comparison.
+        import oracle
+        nr = a.cpu_rays
+        rbc = {k: v.cpu() for k, v in rb.items()}
+        rbc["ray_o"], rbc["ray_d"] = rbc["ray_o"][:nr], rbc["ray_d"][:nr]
+        _, zc = oracle.sampling.sample_along_camera_ray(rbc["ray_o"], rbc["ray_d"], rbc["depth_range"],
+                                                        N_SAMPLES, inv_uniform=True, det=True)
+        zf = [oracle.sampling.sample_fine_pts(True, N_IMPORTANCE, True, N_SAMPLES, rbc, w.clone(), zc)[1]
+              for w in (ret["outputs_coarse"]["weights"][:nr].cpu(), want["outputs_coarse"]["weights"])]
+        same = ((zf[0] - zf[1]).abs().amax(-1) <= 1e-4 * zf[1].abs().amax(-1))
+        # visibility of the fine samples: the GPU pipeline's own points vs the oracle's
+        from gp_nerf_amd import render_ray as rr
+        sv = projector.prepare(rb["camera"], rb["src_rgbs"], rb["src_cameras"], scene.featmaps, scene.deep)
+        rbg = dict(rb)
+        rbg["ray_o"], rbg["ray_d"] = rb["ray_o"][:nr], rb["ray_d"][:nr]
+        pg, _ = rr.sample_fine_pts(True, N_IMPORTANCE, True, N_SAMPLES, rbg,
+                                   ret["outputs_coarse"]["weights"][:nr], zc.to(dev))
+        m_gpu = (projector.compute_fused(pg, sv)[2].reshape(nr, -1, VIEWS) != 0).cpu()
+        pc, _ = oracle.sampling.sample_fine_pts(True, N_IMPORTANCE, True, N_SAMPLES, rbc,
+                                                want["outputs_coarse"]["weights"].clone(), zc)
+        pix, front = oracle.projector.compute_projections(pc, rbc["src_cameras"][0])
+        m_cpu = (oracle.projector.inbound(pix, float(scene.H), float(scene.W)) & front).permute(1, 2, 0)
+        same &= (m_gpu == m_cpu).reshape(nr, -1).all(dim=-1)
         worst = 0.0
         for lvl in ("outputs_coarse", "outputs_fine"):
             for k in ("rgb", "depth", "weights", "feats_out"):
-                x, y = ret[lvl][k][:a.cpu_rays].cpu(), want[lvl][k]
+                x, y = ret[lvl][k][:nr].cpu(), want[lvl][k]
+                if lvl == "outputs_fine":
+                    x, y = x[same], y[same]
                 worst = max(worst, float((x - y).abs().max() / max(1.0, float(y.abs().max()))))
         cpu["max_rel_err_gpu_vs_cpu"] = worst
+        cpu["fine_rays_resampled"] = int((~same).sum())
 
     if rank == 0:
         rays = world * CHUNK * a.steps
         line = {
             "metric": "rays_per_sec", "value": rays / elapsed, "unit": "rays/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if a.precision == "fp32" else "f32 (bf16x3 split-operand MFMA, fp32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": "replica_640x480_10views render_rays chunk=4096 rays/GPU, "
-                                   "coarse 48 + importance 16 (48- and 64-sample passes), fp32",
+            "config": {"workload": "replica_640x480_10views render_rays chunk=%d rays/GPU, "
+                                   "coarse 48 + importance 16 (48- and 64-sample passes)" % CHUNK,
+                       "precision": a.precision,
                        "rays_per_step_per_gpu": CHUNK, "samples": [N_SAMPLES, N_SAMPLES + N_IMPORTANCE],
                        "views": VIEWS, "parallelism": "ray-sharded x%d" % world},
-            "roofline": roofline, "cpu_baseline": cpu, "stage_ms_one_step": stages,
+            "roofline": roofline, "cpu_baseline": cpu,
+            "fp32_exact" if a.precision == "bf16x3" else "bf16x3": other,
+            "stage_ms_one_step": stages,
         }
         print(json.dumps(line))
     if world > 1:

@@ -349,6 +349,94 @@ def test_gnt_stages(dev, net, prec, S):
     assert not bad, "stage errors above %g: %s (all: %s)" % (STAGE_TOL[prec], bad, errs)
 
 
+def test_gnt_stages_many_tiles(dev, net, prec):
+    """The per-point kernels are persistent: a wave walks several tiles and fetches the next tile's
+    inputs ahead.  The golden cases are smaller than one tile per wave, so this case (70,400 points,
+    1,100 rays; random inputs, visibility patterns incl. fully masked points) drives every wave
+    through the multi-tile paths; each kernel is checked against the oracle's building blocks."""
+    import torch.nn.functional as F
+    from gp_nerf_amd import _lib
+    L = _lib.lib()
+    sd = cases.weights()
+    R, S, V = 1100, 64, 10
+    N = R * S
+    gcpu = torch.Generator().manual_seed(11)
+    q = torch.randn(R, S, 64, generator=gcpu)
+    feat = torch.randn(R, S, V, 64, generator=gcpu)
+    rdiff = torch.randn(R, S, V, 4, generator=gcpu)
+    mask = (torch.rand(R, S, V, 1, generator=gcpu) < 0.6).float()
+    mask[::7, ::5] = 0.0          # points without any visible view
+    mask[3::11, 1::3] = 1.0       # points visible everywhere
+    rgbf = torch.randn(R, S, V, 35, generator=gcpu)
+    emb = torch.randn(N, 128, generator=gcpu)
+    emb[:, 126:] = 0.0
+    W = net._weights()
+    st = _lib.stream()
+    f = lambda t: t.to(dev).float().contiguous()
+    e = lambda *s_: torch.empty(s_, device=dev)
+    errs = {}
+    # view attention (layer 0), identity order and visibility-sorted order
+    p = "view_crosstrans.0"
+    x, attn = oracle.gnt.attention2d(sd, p + ".attn", oracle.gnt._ln(sd, p + ".attn_norm", q, 1e-6),
+                                     feat, rdiff, mask)
+    want_q = (x + q).reshape(N, 64)
+    qd, fd, rd, mk = f(q.reshape(N, 64)), f(feat.reshape(N, V, 64)), f(rdiff.reshape(N, V, 4)), f(mask.reshape(N, V))
+    perm2 = torch.empty(2 * N, dtype=torch.int32, device=dev)
+    scr = torch.empty(L.gpn_vis_order_scratch_bytes(), dtype=torch.uint8, device=dev)
+    _lib.check(L.gpn_vis_order(_lib.ptr(mk), N, V, _lib.ptr(perm2), _lib.ptr(scr), st), "vis_order")
+    assert torch.equal(torch.sort(perm2[:N].long())[0].cpu(), torch.arange(N))
+    outs = []
+    for pm in (None, perm2):
+        qo, lg, stt = e(N, 64), torch.zeros(N, V, 64, device=dev), e(N, 2, 64)
+        _lib.check(L.gpn_view_attn(C.byref(W.view[0]), _lib.ptr(qd), _lib.ptr(fd), _lib.ptr(rd), _lib.ptr(mk),
+                                   _lib.ptr(pm) if pm is not None else None, N, V, _lib.ptr(qo),
+                                   _lib.ptr(lg), 64, _lib.ptr(stt), 128, st), "view")
+        outs.append((qo, lg, stt))
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(*outs)), "visibility-sorted order changed the results"
+    qo, lg, stt = outs[0]
+    errs["view_attn"] = rel(qo, want_q)
+    vis = mk.reshape(N, V, 1) != 0
+    a2 = torch.where(vis, torch.exp(lg - stt[:, 0][:, None]) * stt[:, 1][:, None], torch.zeros_like(lg))
+    a2 = torch.where(vis.any(dim=1, keepdim=True), a2, torch.full_like(lg, 1.0 / V))
+    errs["attn2d"] = rel(a2, attn.reshape(N, V, 64))
+    # feed-forward
+    want = q + oracle.gnt.feed_forward(sd, p + ".ff", oracle.gnt._ln(sd, p + ".ff_norm", q, 1e-6))
+    out = e(N, 64)
+    vl = W.view[0]
+    _lib.check(L.gpn_ff(vl.ff_norm_w, vl.ff_norm_b, C.byref(vl.ff1), C.byref(vl.ff2), _lib.ptr(qd), N,
+                        _lib.ptr(out), st), "ff")
+    errs["ff"] = rel(out, want.reshape(N, 64))
+    # rgbfeat
+    want = oracle.gnt._lin(sd, "rgbfeat_fc.2", F.relu(oracle.gnt._lin(sd, "rgbfeat_fc.0", rgbf)))
+    fo, q0 = e(N, V, 64), e(N, 64)
+    rgbf_d = f(rgbf.reshape(N, V, 35))
+    _lib.check(L.gpn_rgbfeat(C.byref(W.rgbfeat0), C.byref(W.rgbfeat2), _lib.ptr(rgbf_d), N, V, 35,
+                             _lib.ptr(fo), _lib.ptr(q0), st), "rgbfeat")
+    errs["feat"] = rel(fo, want.reshape(N, V, 64))
+    errs["q0"] = rel(q0, want.max(dim=2)[0].reshape(N, 64))
+    # q positional MLP (layer 0)
+    xin = torch.cat([q.reshape(N, 64), emb[:, :126]], -1)
+    want = oracle.gnt._lin(sd, "q_fcs.0.2", F.relu(oracle.gnt._lin(sd, "q_fcs.0.0", xin)))
+    out, emb_d = e(N, 64), f(emb)
+    _lib.check(L.gpn_qpos(C.byref(W.qfc0[0]), C.byref(W.qfc2[0]), _lib.ptr(qd), _lib.ptr(emb_d), N,
+                          _lib.ptr(out), st), "qpos")
+    errs["qpos"] = rel(out, want)
+    # ray attention (layer 0)
+    pr = "view_selftrans.0"
+    o, A = oracle.gnt.ray_attention(sd, pr + ".attn", oracle.gnt._ln(sd, pr + ".attn_norm", q, 1e-6))
+    xo, ab, wt = e(R, S, 64), e(R, S, 4), e(R, S)
+    q3 = f(q)
+    _lib.check(L.gpn_ray_attn(C.byref(W.ray[0]), _lib.ptr(q3), R, S, _lib.ptr(xo), _lib.ptr(ab), 4,
+                              _lib.ptr(wt), st), "ray")
+    errs["ray_attn"] = rel(xo, o + q)
+    errs["abar"] = rel(ab, A.mean(dim=2).permute(0, 2, 1))
+    errs["weights"] = rel(wt, A.mean(dim=1)[:, 0])
+    torch.cuda.synchronize()
+    print("many-tile stage errors [%s]: %s" % (prec, {k: "%.1e" % v for k, v in errs.items()}))
+    bad = {k: v for k, v in errs.items() if not v < STAGE_TOL[prec]}
+    assert not bad, "stage errors above %g: %s" % (STAGE_TOL[prec], bad)
+
+
 @pytest.mark.parametrize("S", [48, 64])
 def test_gnt_forward_vs_golden(dev, net, prec, golden, S):
     g = golden("g2_gnt_s%d" % S)

@@ -125,9 +125,10 @@ class GNT(nn.Module):
         self.in_feat_ch = in_feat_ch
         self._wcache = None
         self._ws = None
-        # 'fp32': exact fp32 MFMA.  'bf16x3': split-bf16 MFMA with fp32 accumulation (~6e-6 of the
-        # tensor scale end to end, 5x the matrix rate); see include/gpnerf_hip.h.
-        self.precision = "fp32"
+        # 'bf16x3' (default): split-bf16 MFMA with fp32 accumulation, ~5e-6 of the tensor scale end to
+        # end against the reference's golden vectors (bar: 1e-4), 1.45x the rays/s of 'fp32'.
+        # 'fp32': exact fp32 MFMA in the reference's operation order.  See include/gpnerf_hip.h.
+        self.precision = "bf16x3"
 
     # ------------------------------------------------------------------ weights -> C struct
     def _weights(self):

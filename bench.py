@@ -244,7 +244,7 @@ def main():
         ex_flops = (VIEWS * live * VIEW_EXEC_FLOPS_PER_PAIR[a.precision] +
                     VIEW_EXEC_FLOPS_PER_POINT[a.precision]) * pts_per_launch
         alg_bytes = (VIEWS * live * (256 + 16) + VIEWS * vstat["visible_pair_fraction"] * 256 +
-                     256 + 256 + 512 + 8) * pts_per_launch
+                     256 + 256 + 256 + 8) * pts_per_launch
         roofline.update({
             "executed_mfma_tflops": ex_flops / (mean_ms * 1e-3) / 1e12,
             "algorithmic_bytes_per_launch": alg_bytes,

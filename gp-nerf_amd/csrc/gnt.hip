@@ -145,12 +145,18 @@ k_rgbfeat(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ rgb_feat
         y[M] = ld4(b2 + 16 * M + 4 * g);
       }
       lin<SPL, 4, 4>(W2, LDW, h, y, lane);
-      float* out = feat + ((size_t)nc * V + v) * C64 + 4 * g;
+      if constexpr (SPL) {
+        // split encoding of a feature row (gnt_mfma.h: feat_row_*): the operand split is done once
+        // here instead of once per transformer layer in k_view_attn
+        if (valid) store_feat_split(feat + ((size_t)nc * V + v) * C64, y, g);
+      } else {
+        float* out = feat + ((size_t)nc * V + v) * C64 + 4 * g;
 #pragma unroll
-      for (int M = 0; M < 4; ++M) {
-        if (valid) st4(out + 16 * M, y[M]);
-        qmax[M] = f4_max(qmax[M], y[M]);
+        for (int M = 0; M < 4; ++M)
+          if (valid) st4(out + 16 * M, y[M]);
       }
+#pragma unroll
+      for (int M = 0; M < 4; ++M) qmax[M] = f4_max(qmax[M], y[M]);
     }
     if (valid) {
 #pragma unroll
@@ -407,14 +413,14 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
   unsigned vis;
   point_of(tile, n, vis);
   unsigned live = live_of(vis);
+  // feature row of the current view: fp32 T-tiles, or (split mode) the two pre-split K pairs
   f4 xq[4], fcur[4];
   float rdcur;
 #pragma unroll
   for (int T = 0; T < 4; ++T) xq[T] = ld4(q_in + (size_t)n * C64 + 16 * T + 4 * g);
   {
     const int v0 = __builtin_ctz(live);
-#pragma unroll
-    for (int T = 0; T < 4; ++T) fcur[T] = ld4(feat + ((size_t)n * V + v0) * C64 + 16 * T + 4 * g);
+    load_feat_row<SPL>(feat + ((size_t)n * V + v0) * C64, g, fcur);
     rdcur = ray_diff[((size_t)n * V + v0) * 4 + g];
   }
 
@@ -465,7 +471,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
       // The next LIVE view (in the last iteration: the first live view of the next tile) is fetched
       // into the same registers as soon as this view's features have been consumed.
       const size_t pair_next = live ? (size_t)n * V + __builtin_ctz(live) : (size_t)n_next * V + v0_next;
-      const float* fsrc = feat + pair_next * C64 + 4 * g;
+      const float* fsrc = feat + pair_next * C64;
       const float* rsrc = ray_diff + pair_next * 4 + g;
       const float rd = rdcur;
       rdcur = *rsrc;
@@ -483,11 +489,10 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
         // v + pos = (Wv Wk) f + P2 h + b ; attn hidden = (A0 Wk) f + (A0 P2) h + aq : every product
         // reads the split of f and h made once here
         XS xs[3];
-        xs[0] = split8(fcur[0], fcur[1]);
-        xs[1] = split8(fcur[2], fcur[3]);
+        xs[0] = feat_pair(fcur[0], fcur[1]);
+        xs[1] = feat_pair(fcur[2], fcur[3]);
         xs[2] = split8(ph, f4_zero());
-#pragma unroll
-        for (int T = 0; T < 4; ++T) fcur[T] = ld4(fsrc + 16 * T);
+        load_feat_row<SPL>(fsrc, g, fcur);
         lin_Sx<4, 4>(L.Wv, xs, vp, lane);
         lin_Sx<1, 4>(L.P2, xs + 2, vp, lane);
         f4 ah = aq;
@@ -498,9 +503,13 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
         f4 k[4];
 #pragma unroll
         for (int M = 0; M < 4; ++M) k[M] = f4_zero();
-        lin<SPL, 4, 4>(L.Wk, LDW, fcur, k, lane);   // k = k_fc(feat)
-#pragma unroll
-        for (int T = 0; T < 4; ++T) fcur[T] = ld4(fsrc + 16 * T);
+        if constexpr (SPL) {
+          const XS xf[2] = {feat_pair(fcur[0], fcur[1]), feat_pair(fcur[2], fcur[3])};
+          lin_Sx<4, 4>(L.Wk, xf, k, lane);
+        } else {
+          lin_T<4, 4>(L.Wk, LDW, fcur, k, lane);   // k = k_fc(feat)
+        }
+        load_feat_row<SPL>(fsrc, g, fcur);
         f4 pos[4];
 #pragma unroll
         for (int M = 0; M < 4; ++M) pos[M] = vp[M];
@@ -519,9 +528,11 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
         ah = f4_relu(ah);
         lin<SPL, 1, 4>(L.A2, VA_LD8, &ah, a, lane);
       }
-      if (mk == 0.0f) {
+      if (__any(mk == 0.0f)) {  // tiles are visibility-homogeneous: usually no lane is masked here
+        if (mk == 0.0f) {
 #pragma unroll
-        for (int M = 0; M < 4; ++M) a[M] = f4_splat(-1e9f);  // masked_fill (:83)
+          for (int M = 0; M < 4; ++M) a[M] = f4_splat(-1e9f);  // masked_fill (:83)
+        }
       }
       if (logits != nullptr && valid && mk != 0.0f) {  // masked pairs are never read back
         float* lo = logits + ((size_t)n * V + v) * logits_ld + 4 * g;
@@ -561,11 +572,13 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
     if (valid) {
 #pragma unroll
       for (int M = 0; M < 4; ++M) st4(q_out + (size_t)n * C64 + 16 * M + 4 * g, y[M] + xr[M]);
-      if (stats != nullptr) {
+      if (stats != nullptr) {  // log-sum-exp over the views: softmax weight = exp(logit - lse)
 #pragma unroll
         for (int M = 0; M < 4; ++M) {
-          st4(stats + (size_t)n * stats_ld + 16 * M + 4 * g, mrun[M]);
-          st4(stats + (size_t)n * stats_ld + 64 + 16 * M + 4 * g, rl[M]);
+          f4 lse;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lse[r] = mrun[M][r] + logf(lrun[M][r]);
+          st4(stats + (size_t)n * stats_ld + 16 * M + 4 * g, lse);
         }
       }
     }
@@ -1048,14 +1061,13 @@ k_sem(gpn_sem_args_t a) {
     // attention of every layer, the sample position, the next sample's mask
     const float mv = mv_next;
     if (s + 1 < S) mv_next = lane < V ? a.mask[(n + 1) * V + lane] : 0.0f;
-    float mx[DEPTH], rl[DEPTH], ab[DEPTH];
+    float lse[DEPTH], ab[DEPTH];
     const float* abp = a.abar + n * (DEPTH * 4);
-    const float* stp = a.stats + n * (DEPTH * 128);
+    const float* stp = a.stats + n * (DEPTH * C64);
 #pragma unroll
     for (int l = 0; l < DEPTH; ++l) {
       ab[l] = abp[4 * l + head];
-      mx[l] = __builtin_nontemporal_load(stp + (128 * l + lane));
-      rl[l] = __builtin_nontemporal_load(stp + (128 * l + 64 + lane));
+      lse[l] = __builtin_nontemporal_load(stp + (C64 * l + lane));
     }
     float px = 0.f, py = 0.f, pz = 0.f;
     if (!dense) px = a.xyz[n * 3 + 0], py = a.xyz[n * 3 + 1], pz = a.xyz[n * 3 + 2];
@@ -1115,7 +1127,7 @@ k_sem(gpn_sem_args_t a) {
         w3 = 0.f, w2 = 0.f;
 #pragma unroll
         for (int l = 0; l < DEPTH; ++l) {
-          const float at = __expf(lg[l] - mx[l]) * rl[l];
+          const float at = __expf(lg[l] - lse[l]);
           w3 += at;
           w2 += ab[l] * at;
         }
@@ -1305,8 +1317,8 @@ extern "C" int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const
                   aligned16(stats), "gpn_view_attn: tensors must be 16-byte aligned");
   GPN_REQUIRE(!logits || (logits_ld >= C64 && logits_ld % 4 == 0),
               "gpn_view_attn: logits_ld must be a multiple of 4 and >= %d (got %d)", C64, logits_ld);
-  GPN_REQUIRE(!stats || (stats_ld >= 2 * C64 && stats_ld % 4 == 0),
-              "gpn_view_attn: stats_ld must be a multiple of 4 and >= %d (got %d)", 2 * C64, stats_ld);
+  GPN_REQUIRE(!stats || (stats_ld >= C64 && stats_ld % 4 == 0),
+              "gpn_view_attn: stats_ld must be a multiple of 4 and >= %d (got %d)", C64, stats_ld);
   const bool spl = gpn_precision() == GPN_PREC_BF16X3;
   const bool fold = spl && L->folded != nullptr;
   const size_t lds = sizeof(float) * view_lds_floats(spl);
@@ -1512,7 +1524,7 @@ static GntWs gnt_ws_layout(int R, int S, int V, int depth) {
   w.feat = o, o += align_up(N * V * C64 * f);
   w.q = o, o += align_up(N * C64 * f);
   w.logits = o, o += align_up(N * V * depth * C64 * f);  // [N,V,depth,64]
-  w.stats = o, o += align_up(N * depth * 128 * f);        // [N,depth,128]
+  w.stats = o, o += align_up(N * depth * C64 * f);        // [N,depth,64]
   w.abar = o, o += align_up(N * depth * 4 * f);           // [R,S,depth,4]
   w.weights = o, o += align_up(N * f);
   w.pre = o, o += align_up((size_t)R * GPN_SEM * f);
@@ -1563,11 +1575,11 @@ extern "C" int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat
   for (int l = 0; l < D; ++l) {
     // side outputs for the semantic aggregation, interleaved over the layers
     float* lg = sem ? reinterpret_cast<float*>(ws + L.logits) + l * C64 : nullptr;
-    float* st = sem ? reinterpret_cast<float*>(ws + L.stats) + l * 128 : nullptr;
+    float* st = sem ? reinterpret_cast<float*>(ws + L.stats) + l * C64 : nullptr;
     float* ab = sem ? reinterpret_cast<float*>(ws + L.abar) + l * 4 : nullptr;
     const gpn_view_layer_t* vl = &W->view[l];
     const gpn_ray_layer_t* rl = &W->ray[l];
-    if ((rc = gpn_view_attn(vl, q, feat, ray_diff, mask, perm, (int)N, V, q, lg, D * C64, st, D * 128,
+    if ((rc = gpn_view_attn(vl, q, feat, ray_diff, mask, perm, (int)N, V, q, lg, D * C64, st, D * C64,
                             stream)))
       return rc;
     if ((rc = gpn_ff(vl->ff_norm_w, vl->ff_norm_b, &vl->ff1, &vl->ff2, q, (int)N, q, stream))) return rc;

@@ -217,6 +217,41 @@ __device__ __forceinline__ XS split8(f4 a, f4 b) {
   return s;
 }
 
+// Split encoding of a 64-channel feature row in global memory (the `feat` tensor in bf16x3 mode):
+// 16 units of 16 bytes, unit ((P*4 + g)*2 + hm) = the hi (hm = 0) or mid (hm = 1) piece of the 8
+// channels {32P+4g+r, 32P+16+4g+r : r < 4} -- exactly the B fragment lane (., g) feeds to K pair P.
+// Same 256 bytes per row as fp32.
+__device__ __forceinline__ void store_feat_split(float* row, const f4* y, int g) {
+  bf8* u = reinterpret_cast<bf8*>(row);
+#pragma unroll
+  for (int P = 0; P < 2; ++P) {
+    const XS s = split8(y[2 * P], y[2 * P + 1]);
+    u[(P * 4 + g) * 2] = s.hi;
+    u[(P * 4 + g) * 2 + 1] = s.mid;
+  }
+}
+// Row -> registers: fp32 mode, the four T-tiles; split mode, f[2P] = hi and f[2P+1] = mid of K pair P
+// (raw 16-byte units held in f4 registers).
+template <bool SP>
+__device__ __forceinline__ void load_feat_row(const float* row, int g, f4* f) {
+  if constexpr (SP) {
+#pragma unroll
+    for (int P = 0; P < 2; ++P) {
+      f[2 * P] = ld4(row + ((P * 4 + g) * 2) * 4);
+      f[2 * P + 1] = ld4(row + ((P * 4 + g) * 2 + 1) * 4);
+    }
+  } else {
+#pragma unroll
+    for (int T = 0; T < 4; ++T) f[T] = ld4(row + 16 * T + 4 * g);
+  }
+}
+__device__ __forceinline__ XS feat_pair(f4 hi, f4 mid) {
+  XS s;
+  s.hi = __builtin_bit_cast(bf8, hi);
+  s.mid = __builtin_bit_cast(bf8, mid);
+  return s;
+}
+
 // floats of LDS taken by the weight image of a [prow x 16*kt] matrix
 __host__ __device__ constexpr int wimg_floats(bool split, int prow, int kt, int ld) {
   return split ? ((prow + 15) / 16) * ((kt + 1) / 2) * 2 * 64 * 4 : prow * ld;

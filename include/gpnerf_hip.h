@@ -146,7 +146,12 @@ typedef struct {                 /* GNT, transformer_network.py:221-294 (state-d
 int gpn_posenc(const float* pts, const float* ray_d, int R, int S, float* emb, gpn_stream_t stream);
 
 /* rgbfeat_fc + max over views, transformer_network.py:309-311.
- * rgb_feat [N,V,3+F] -> feat [N,V,C], q0 [N,C]. */
+ * rgb_feat [N,V,3+F] -> feat [N,V,C], q0 [N,C].
+ * `feat` is the tensor gpn_view_attn reads.  In GPN_PREC_FP32 mode it is plain fp32.  In
+ * GPN_PREC_BF16X3 mode every row of C = 64 channels is stored in the operand format of that mode (same
+ * 256 bytes): 16 units of 8 bf16, unit ((P*4 + g)*2 + hm), P < 2, g < 4, holding the high (hm = 0)
+ * or the residual (hm = 1) bf16 piece of channels {32P+4g+r, 32P+16+4g+r : r < 4}; value = hi + mid.
+ * Both calls must run in the same mode. */
 int gpn_rgbfeat(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* rgb_feat, int N,
                 int V, int in_ch, float* feat, float* q0, gpn_stream_t stream);
 
@@ -156,10 +161,10 @@ int gpn_rgbfeat(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* r
  * logits: C pre-softmax attention values per VISIBLE (point, view) pair (mask != 0; entries of
  * masked pairs are left unwritten: their softmax weight is exactly 0, or exactly 1/V when the
  * point has no visible view at all), the row of pair (n, v) starting at logits[(n*V+v)*logits_ld];
- * stats: (max_v [C] | 1/sum_v exp [C]) per point, row n starting at stats[n*stats_ld], so that the
- * per-channel view softmax of line :84 is exp(logit-max)*rsum.  logits_ld >= C and stats_ld >= 2C
- * (multiples of 4) let the caller interleave the layers (see gpn_sem_args_t); logits/stats may be
- * NULL. */
+ * stats: log-sum-exp over the views, C values per point, row n starting at stats[n*stats_ld], so
+ * that the per-channel view softmax of line :84 is exp(logit - lse).  logits_ld >= C and
+ * stats_ld >= C (multiples of 4) let the caller interleave the layers (see gpn_sem_args_t);
+ * logits/stats may be NULL. */
 int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const float* feat,
                   const float* ray_diff, const float* mask, const int32_t* perm, int N, int V,
                   float* q_out, float* logits, int logits_ld, float* stats, int stats_ld,
@@ -205,7 +210,7 @@ typedef struct {
   /* per-layer side outputs of gpn_view_attn / gpn_ray_attn, interleaved over the layers so that
    * everything one (sample, view) needs is contiguous: */
   const float* logits;                /* [N,V,depth,C]  (layer l: logits + l*C,  ld = depth*C)  */
-  const float* stats;                 /* [N,depth,2,C]  (layer l: stats + l*2C,  ld = depth*2C) */
+  const float* stats;                 /* [N,depth,C]    (layer l: stats + l*C,   ld = depth*C)  */
   const float* abar;                  /* [R,S,depth,4]  (layer l: abar + l*4,    ld = depth*4)  */
   const float* mask;                  /* [N,V] */
   /* deep-semantic source: either a materialised tensor ... */

@@ -52,6 +52,29 @@ def prec(request, net):
 STAGE_TOL = {"fp32": 2e-5, "bf16x3": 2e-5}
 
 
+def enc_feat(x, prec):
+    """[..., 64] fp32 feature rows -> the layout gpn_view_attn reads in mode `prec`
+    (bf16x3: the split encoding documented at gpn_rgbfeat in include/gpnerf_hip.h)."""
+    if prec != "bf16x3":
+        return x
+    lead = x.shape[:-1]
+    t = x.reshape(lead + (2, 2, 4, 4)).permute(*range(len(lead)), -4, -2, -3, -1)  # [..., P, g, half, r]
+    t = t.reshape(lead + (2, 4, 8))
+    hi = t.bfloat16()
+    mid = (t - hi.float()).bfloat16()
+    return torch.stack([hi, mid], dim=-2).contiguous().view(torch.float32).reshape(lead + (64,))
+
+
+def dec_feat(buf, prec):
+    """Inverse of enc_feat (hi + mid)."""
+    if prec != "bf16x3":
+        return buf
+    lead = buf.shape[:-1]
+    t = buf.contiguous().view(torch.bfloat16).reshape(lead + (2, 4, 2, 8)).float().sum(dim=-2)  # [..., P, g, 8]
+    t = t.reshape(lead + (2, 4, 2, 4)).permute(*range(len(lead)), -4, -2, -3, -1)  # [..., P, half, g, r]
+    return t.reshape(lead + (64,))
+
+
 def rel(a, b):
     """max |a-b| relative to the scale of b (at least 1)."""
     a = a.detach().float().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
@@ -272,17 +295,17 @@ def test_gnt_stages(dev, net, prec, S):
     feat, q0 = e(N, V, 64), e(N, 64)
     _lib.check(L.gpn_rgbfeat(C.byref(W.rgbfeat0), C.byref(W.rgbfeat2), _lib.ptr(rgbf_d), N, V,
                              35, _lib.ptr(feat), _lib.ptr(q0), st), "rgbfeat")
-    errs["feat"] = rel(feat, rec["feat"].reshape(N, V, 64))
+    errs["feat"] = rel(dec_feat(feat, prec), rec["feat"].reshape(N, V, 64))
     errs["q0"] = rel(q0, rec["q0"].reshape(N, 64))
     rd, mk = f(c["ray_diff"]), f(c["mask"])
-    feat_ref = f(rec["feat"].reshape(N, V, 64))
+    feat_ref = f(enc_feat(rec["feat"].reshape(N, V, 64), prec))
     emb_ref = f(want)
     for l in (0, 1, 7):
         q_in = f((rec["q0"] if l == 0 else rec["q_ray"][l - 1]).reshape(N, 64))
-        qo, lg, stt = e(N, 64), e(N, V, 64), e(N, 2, 64)
+        qo, lg, stt = e(N, 64), e(N, V, 64), e(N, 64)
         _lib.check(L.gpn_view_attn(C.byref(W.view[l]), _lib.ptr(q_in), _lib.ptr(feat_ref), _lib.ptr(rd),
                                    _lib.ptr(mk), None, N, V, _lib.ptr(qo), _lib.ptr(lg), 64,
-                                   _lib.ptr(stt), 128, st), "view")
+                                   _lib.ptr(stt), 64, st), "view")
         errs["view_attn%d" % l] = rel(qo, rec["q_view_attn"][l].reshape(N, 64))
         if l == 0:  # the same layer without the folded weight products (reference operation order)
             plain = type(W.view[l])()
@@ -290,7 +313,7 @@ def test_gnt_stages(dev, net, prec, S):
             plain.folded = None
             qo_p = e(N, 64)
             _lib.check(L.gpn_view_attn(C.byref(plain), _lib.ptr(q_in), _lib.ptr(feat_ref), _lib.ptr(rd),
-                                       _lib.ptr(mk), None, N, V, _lib.ptr(qo_p), None, 64, None, 128, st),
+                                       _lib.ptr(mk), None, N, V, _lib.ptr(qo_p), None, 64, None, 64, st),
                        "view-unfolded")
             errs["view_attn_unfolded"] = rel(qo_p, rec["q_view_attn"][l].reshape(N, 64))
         # same launch in visibility-sorted order: bit-identical outputs
@@ -305,17 +328,17 @@ def test_gnt_stages(dev, net, prec, S):
         assert bool((cost[1:] <= cost[:-1]).all()), "perm is not ordered by decreasing cost class"
         runs = int((key[1:] != key[:-1]).sum()) + 1
         assert runs == int(torch.unique(key).numel()), "a visibility pattern is split across bins"
-        qo2, lg2, stt2 = e(N, 64), torch.zeros_like(lg), e(N, 2, 64)
+        qo2, lg2, stt2 = e(N, 64), torch.zeros_like(lg), e(N, 64)
         lg.masked_fill_(mk.reshape(N, V, 1) == 0, 0.0)  # unwritten (masked) entries -> 0 on both sides
         _lib.check(L.gpn_view_attn(C.byref(W.view[l]), _lib.ptr(q_in), _lib.ptr(feat_ref), _lib.ptr(rd),
                                    _lib.ptr(mk), _lib.ptr(perm2), N, V, _lib.ptr(qo2), _lib.ptr(lg2), 64,
-                                   _lib.ptr(stt2), 128, st), "view-perm")
+                                   _lib.ptr(stt2), 64, st), "view-perm")
         lg2.masked_fill_(mk.reshape(N, V, 1) == 0, 0.0)
         assert torch.equal(qo, qo2) and torch.equal(stt, stt2) and torch.equal(lg, lg2), \
             "visibility-sorted order changed the results"
         # logits of masked pairs are never written: weight 0, or 1/V for an all-masked point
         vis = mk.reshape(N, V, 1) != 0
-        attn = torch.where(vis, torch.exp(lg - stt[:, 0][:, None]) * stt[:, 1][:, None],
+        attn = torch.where(vis, torch.exp(lg - stt[:, None]),
                            torch.zeros_like(lg))
         attn = torch.where(vis.any(dim=1, keepdim=True), attn, torch.full_like(lg, 1.0 / V))
         errs["attn2d%d" % l] = rel(attn, rec["attn2d"][l].reshape(N, V, 64))
@@ -380,23 +403,24 @@ def test_gnt_stages_many_tiles(dev, net, prec):
     x, attn = oracle.gnt.attention2d(sd, p + ".attn", oracle.gnt._ln(sd, p + ".attn_norm", q, 1e-6),
                                      feat, rdiff, mask)
     want_q = (x + q).reshape(N, 64)
-    qd, fd, rd, mk = f(q.reshape(N, 64)), f(feat.reshape(N, V, 64)), f(rdiff.reshape(N, V, 4)), f(mask.reshape(N, V))
+    qd, fd = f(q.reshape(N, 64)), f(enc_feat(feat.reshape(N, V, 64), prec))
+    rd, mk = f(rdiff.reshape(N, V, 4)), f(mask.reshape(N, V))
     perm2 = torch.empty(2 * N, dtype=torch.int32, device=dev)
     scr = torch.empty(L.gpn_vis_order_scratch_bytes(), dtype=torch.uint8, device=dev)
     _lib.check(L.gpn_vis_order(_lib.ptr(mk), N, V, _lib.ptr(perm2), _lib.ptr(scr), st), "vis_order")
     assert torch.equal(torch.sort(perm2[:N].long())[0].cpu(), torch.arange(N))
     outs = []
     for pm in (None, perm2):
-        qo, lg, stt = e(N, 64), torch.zeros(N, V, 64, device=dev), e(N, 2, 64)
+        qo, lg, stt = e(N, 64), torch.zeros(N, V, 64, device=dev), e(N, 64)
         _lib.check(L.gpn_view_attn(C.byref(W.view[0]), _lib.ptr(qd), _lib.ptr(fd), _lib.ptr(rd), _lib.ptr(mk),
                                    _lib.ptr(pm) if pm is not None else None, N, V, _lib.ptr(qo),
-                                   _lib.ptr(lg), 64, _lib.ptr(stt), 128, st), "view")
+                                   _lib.ptr(lg), 64, _lib.ptr(stt), 64, st), "view")
         outs.append((qo, lg, stt))
     assert all(torch.equal(a_, b_) for a_, b_ in zip(*outs)), "visibility-sorted order changed the results"
     qo, lg, stt = outs[0]
     errs["view_attn"] = rel(qo, want_q)
     vis = mk.reshape(N, V, 1) != 0
-    a2 = torch.where(vis, torch.exp(lg - stt[:, 0][:, None]) * stt[:, 1][:, None], torch.zeros_like(lg))
+    a2 = torch.where(vis, torch.exp(lg - stt[:, None]), torch.zeros_like(lg))
     a2 = torch.where(vis.any(dim=1, keepdim=True), a2, torch.full_like(lg, 1.0 / V))
     errs["attn2d"] = rel(a2, attn.reshape(N, V, 64))
     # feed-forward
@@ -412,7 +436,7 @@ def test_gnt_stages_many_tiles(dev, net, prec):
     rgbf_d = f(rgbf.reshape(N, V, 35))
     _lib.check(L.gpn_rgbfeat(C.byref(W.rgbfeat0), C.byref(W.rgbfeat2), _lib.ptr(rgbf_d), N, V, 35,
                              _lib.ptr(fo), _lib.ptr(q0), st), "rgbfeat")
-    errs["feat"] = rel(fo, want.reshape(N, V, 64))
+    errs["feat"] = rel(dec_feat(fo, prec), want.reshape(N, V, 64))
     errs["q0"] = rel(q0, want.max(dim=2)[0].reshape(N, 64))
     # q positional MLP (layer 0)
     xin = torch.cat([q.reshape(N, 64), emb[:, :126]], -1)

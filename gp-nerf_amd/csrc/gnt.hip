@@ -564,7 +564,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
 #pragma unroll
     for (int M = 0; M < 4; ++M) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) rl[M][r] = 1.0f / lrun[M][r];
+      for (int r = 0; r < 4; ++r) rl[M][r] = __builtin_amdgcn_rcpf(lrun[M][r]);  // v_rcp_f32, 1 ulp
       xs[M] = acc[M] * rl[M];
       y[M] = ld4(L.bO + 16 * M + 4 * g);
     }
@@ -577,7 +577,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
         for (int M = 0; M < 4; ++M) {
           f4 lse;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) lse[r] = mrun[M][r] + logf(lrun[M][r]);
+          for (int r = 0; r < 4; ++r) lse[r] = mrun[M][r] + __logf(lrun[M][r]);
           st4(stats + (size_t)n * stats_ld + 16 * M + 4 * g, lse);
         }
       }
@@ -882,6 +882,14 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
     }
     __syncthreads();
 
+    // scores / sqrt(16): scale q once (exact, a power of two) instead of every score; in split mode
+    // log2(e) rides along so that the softmax is a bare v_exp_f32 (2^x)
+    {
+      const float qscale = SPL ? 0.25f * 1.44269504088896341f : 0.25f;
+#pragma unroll
+      for (int M = 0; M < 4; ++M) qT[M] = qT[M] * f4_splat(qscale);
+    }
+    const bool all_q = __all(qvalid);  // no padding query in this tile (S multiple of 16, or not the last tile)
     f4 oT[4], wacc[NT];
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) wacc[kt] = f4_zero();
@@ -920,23 +928,23 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
       float mx = -INFINITY;
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
-        sT[kt] = sT[kt] * f4_splat(0.25f);
         if (kt == NT - 1) {  // only the last key tile can hold padding keys
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (16 * kt + 4 * g + r >= S) sT[kt][r] = -INFINITY;
         }
-        mx = fmaxf(mx, fmaxf(fmaxf(sT[kt].x, sT[kt].y), fmaxf(sT[kt].z, sT[kt].w)));
+        mx = max3_nc(mx, max_nc(sT[kt].x, sT[kt].y), max_nc(sT[kt].z, sT[kt].w));
       }
       mx = max_over_g(mx);
       float sum = 0.f;
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sT[kt][r] = __expf(sT[kt][r] - mx);
+        for (int r = 0; r < 4; ++r)
+          sT[kt][r] = SPL ? __builtin_amdgcn_exp2f(sT[kt][r] - mx) : __expf(sT[kt][r] - mx);
         sum += (sT[kt].x + sT[kt].y) + (sT[kt].z + sT[kt].w);
       }
-      const float inv = 1.0f / sum_over_g(sum);
+      const float inv = __builtin_amdgcn_rcpf(sum_over_g(sum));
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) sT[kt] = sT[kt] * f4_splat(inv);
       // column sums over this wave's queries (for abar) and the query-0 row (for the weights)
@@ -945,7 +953,8 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
         if (t == 0) wacc[kt] = wacc[kt] + sT[kt];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float c = row_sum16(sT[kt][r] * qsel);  // total in lane 15 of each 16-lane row
+          // total in lane 15 of each 16-lane row; padding queries (last tile only) are zeroed
+          const float c = row_sum16(all_q ? sT[kt][r] : sT[kt][r] * qsel);
           if (j == 15) part[((slot * NT + t) * 4 + h) * SP + 16 * kt + 4 * g + r] = c;
         }
       }
@@ -1077,14 +1086,24 @@ k_sem(gpn_sem_args_t a) {
     for (int l = 0; l < DEPTH; ++l) w3u += inv_v, w2u += ab[l] * inv_v;
     f4 acc3a = f4_zero(), acc3b = f4_zero();
     unsigned live = vis != 0 ? vis : all_views;
+    float lgn[DEPTH];  // logits of the next live view, fetched one iteration ahead
+    if (vis != 0) {
+      const float* lgp = a.logits + (n * V + __builtin_ctz(live)) * (DEPTH * C64);
+#pragma unroll
+      for (int l = 0; l < DEPTH; ++l) lgn[l] = __builtin_nontemporal_load(lgp + (C64 * l + lane));
+    }
     while (live) {
       const int v = __builtin_ctz(live);
       live &= live - 1;
       float lg[DEPTH];
       if (vis != 0) {
-        const float* lgp = a.logits + (n * V + v) * (DEPTH * C64);
 #pragma unroll
-        for (int l = 0; l < DEPTH; ++l) lg[l] = __builtin_nontemporal_load(lgp + (C64 * l + lane));
+        for (int l = 0; l < DEPTH; ++l) lg[l] = lgn[l];
+        if (live) {
+          const float* lgp = a.logits + (n * V + __builtin_ctz(live)) * (DEPTH * C64);
+#pragma unroll
+          for (int l = 0; l < DEPTH; ++l) lgn[l] = __builtin_nontemporal_load(lgp + (C64 * l + lane));
+        }
       }
       f4 d0, d1;
       if (dense) {

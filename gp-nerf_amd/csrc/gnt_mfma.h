@@ -28,11 +28,14 @@ __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
 
 __device__ __forceinline__ f4 f4_zero() { return (f4){0.f, 0.f, 0.f, 0.f}; }
 __device__ __forceinline__ f4 f4_splat(float v) { return (f4){v, v, v, v}; }
+// max without the canonicalising pre-pass fmaxf gets (operands are never NaN here)
+__device__ __forceinline__ float max_nc(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
+__device__ __forceinline__ float max3_nc(float a, float b, float c) { return max_nc(max_nc(a, b), c); }
 // max(x, 0) as one v_med3_f32 (fmaxf costs a canonicalising v_max first)
 __device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
 __device__ __forceinline__ f4 f4_relu(f4 v) { return (f4){relu1(v.x), relu1(v.y), relu1(v.z), relu1(v.w)}; }
 __device__ __forceinline__ f4 f4_max(f4 a, f4 b) {
-  return (f4){fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)};
+  return (f4){max_nc(a.x, b.x), max_nc(a.y, b.y), max_nc(a.z, b.z), max_nc(a.w, b.w)};
 }
 __device__ __forceinline__ f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
 __device__ __forceinline__ void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
@@ -96,8 +99,8 @@ __device__ __forceinline__ float sum_over_g(float v) {
   return v;
 }
 __device__ __forceinline__ float max_over_g(float v) {
-  v = fmaxf(v, __shfl_xor(v, 16));
-  v = fmaxf(v, __shfl_xor(v, 32));
+  v = max_nc(v, __shfl_xor(v, 16));
+  v = max_nc(v, __shfl_xor(v, 32));
   return v;
 }
 
@@ -126,7 +129,7 @@ __device__ __forceinline__ void layernorm_T(const f4* x, f4* y, const float* gam
     q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
   }
   const float var = sum_over_g(q) * (1.0f / 64.0f);
-  const float rstd = 1.0f / sqrtf(var + eps);
+  const float rstd = __builtin_amdgcn_rsqf(var + eps);  // v_rsq_f32, 1 ulp (a correctly rounded sqrt + divide costs ~25 instructions)
   const int g = lane >> 4;
 #pragma unroll
   for (int T = 0; T < 4; ++T) {

@@ -13,6 +13,7 @@
 #include "common.h"
 #include "gnt_mfma.h"
 #include "proj_common.h"
+#include <type_traits>
 
 #define C64 64
 // threads per workgroup of the persistent per-point kernels (one 16-point tile per wave)
@@ -32,6 +33,17 @@
 #define FF_NTL 2  // point tiles per wave of the split-mode feed-forward kernel
 #endif
 #define LDW 68  // padded leading dimension of a 64-wide weight matrix in LDS
+#define LOG2E_F 1.44269504088896341f
+#define LN2_F 0.693147180559945309f
+#define VM_HOMOG 0
+#define VM_MASKED 1
+#define VM_ONLINE 2
+#define VA_SLOT_BYTES (4096 + 256)  // one (tile, view) pair: 16 feature rows + 64 ray_diff floats
+#define VA_DMA_OPS 5
+// cache policy of the feature-row DMA: read once per launch -> non-temporal (measured -5 %)
+#ifndef VA_DMA_NT
+#define VA_DMA_NT "nt"
+#endif
 
 extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -339,7 +351,8 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
             const int* __restrict__ perm, long long N, int V, float* __restrict__ q_out,
             float* __restrict__ logits, int logits_ld, float* __restrict__ stats, int stats_ld) {
   const ViewLds L = view_lds<SPL>(smem);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (tile loop, LDS-DMA base)
   stage_w<SPL>(L.Wq, LDW, Lw.q.w, 64, 64, 64, 4, tid, VA_TPB);
   static_assert(SPL || !FOLD, "the folded algorithm exists in split mode only");
   if constexpr (FOLD) {  // Wv slot holds Wv Wk; k itself is never formed
@@ -407,30 +420,131 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
     return (unsigned)__builtin_amdgcn_readfirstlane(m);
   };
 
+  // ---- per-wave ring of two LDS slots filled by LDS-DMA (global_load_lds): the feature row and the
+  // ray_diff entry of a (tile, view) pair are requested TWO view iterations before they are used,
+  // without holding registers meanwhile (at two waves per SIMD one pair in flight per wave does not
+  // cover the HBM latency: the kernel was measured stalled ~70 % of its cycles).  A lane reads back
+  // exactly the bytes it requested (slot + k KiB + 16 lane), so no barrier is involved; the only
+  // ordering is this wave's own s_waitcnt vmcnt before the ds_read (MI355X_MICROARCH.md item 7).
+  // Every view iteration issues exactly VA_DMA_OPS DMA instructions, so the wait count is static.
+  const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(wave);
+  char* ring = reinterpret_cast<char*>(smem + view_lds_floats(SPL)) + wave_u * (2 * VA_SLOT_BYTES);
+  const unsigned ring_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;  // LDS byte address
+  // issue the DMA of pair (point nn of lane j, view vv) into slot `sl`.  Every DMA instruction
+  // fetches WHOLE 128-byte lines (8 lanes x 16 B per line, 8 points per instruction): two
+  // instructions that each take half of every line of a row leave the second one waiting in the
+  // L1 for the first one's fill (measured: TCP_PENDING_STALL 62 % of the kernel's cycles).
+  // Instruction k = 2*h + half covers line h of the rows of points 8*half .. 8*half+7; lane
+  // (jj = lane>>3, r = lane&7) fetches piece c = (r - s) & 7 of point 8*half + jj, s = (jj>>1) +
+  // 4*half: the rotation makes the read-back below bank-conflict free.
+  const int jj8 = lane >> 3, r8 = lane & 7;
+  const int cA = (r8 - (jj8 >> 1)) & 7, cB = (r8 - (jj8 >> 1) - 4) & 7;
+  auto dma_pair = [&](int nn, int vv, unsigned sl) {
+    const int nA = __shfl(nn, jj8), nB = __shfl(nn, 8 + jj8);
+    const char* fa = reinterpret_cast<const char*>(feat) + ((size_t)nA * V + vv) * (C64 * 4) + cA * 16;
+    const char* fb = reinterpret_cast<const char*>(feat) + ((size_t)nB * V + vv) * (C64 * 4) + cB * 16;
+    const char* ra = reinterpret_cast<const char*>(ray_diff) + ((size_t)nn * V + vv) * 16 + g * 4;
+    // instruction offsets apply to the global AND the LDS address: M0 is compensated per piece
+    const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane(ring_lds + sl * VA_SLOT_BYTES);
+    const unsigned m0 = base, m1 = base + 1024, m2 = base + 2048 - 128, m3 = base + 3072 - 128, m4 = base + 4096;
+    unsigned keep;
+    asm volatile(
+        "s_waitcnt lgkmcnt(0)\n\t"  // the slot's previous contents have been read into registers
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off " VA_DMA_NT "\n\t"
+        "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off " VA_DMA_NT "\n\t"
+        "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:128 " VA_DMA_NT "\n\t"
+        "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off offset:128 " VA_DMA_NT "\n\t"
+        "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dword %3, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(fa), "v"(fb), "v"(ra), "s"(m0), "s"(m1), "s"(m2), "s"(m3), "s"(m4)
+        : "memory");
+  };
+  // read a slot back (after the covering wait): unit (line h, piece c) of this lane's point j
+  // landed at piece k = 2h + (j>>3), lane (j&7)*8 + ((c + s_j) & 7), s_j = ((j&7)>>1) + 4*(j>>3)
+  const int sj = ((j & 7) >> 1) + 4 * (j >> 3);
+  int rb_off[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    // split mode: f[2P + hm] = unit (h = P, c = 2g + hm); fp32 mode: f[T] = (h = T>>1, c = 4(T&1) + g)
+    const int h = k >> 1, c = SPL ? 2 * g + (k & 1) : 4 * (k & 1) + g;
+    rb_off[k] = (2 * h + (j >> 3)) * 1024 + ((j & 7) * 8 + ((c + sj) & 7)) * 16;
+  }
+  auto read_slot = [&](unsigned sl, f4* f, float& rd_) {
+    const char* sp = ring + sl * VA_SLOT_BYTES;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) f[k] = *reinterpret_cast<const f4*>(sp + rb_off[k]);
+    rd_ = *reinterpret_cast<const float*>(sp + 4096 + lane * 4);
+  };
+
   long long tile = (long long)blockIdx.x * (VA_TPB / 64) + wave;
   if (tile >= ntiles) return;
-  int n;  // N fits an int (C-ABI)
-  unsigned vis;
+  // points and visibility of the current tile and of the next two; the third one ahead is in flight
+  int n, n1, n2, n3;  // N fits an int (C-ABI)
+  unsigned vis, vis1, vis2, vis3;
   point_of(tile, n, vis);
+  n1 = n2 = n3 = n;
+  vis1 = vis2 = vis3 = vis;
+  if (tile + tstride < ntiles) point_of(tile + tstride, n1, vis1);
+  if (tile + 2 * tstride < ntiles) point_of(tile + 2 * tstride, n2, vis2);
   unsigned live = live_of(vis);
-  // feature row of the current view: fp32 T-tiles, or (split mode) the two pre-split K pairs
-  f4 xq[4], fcur[4];
-  float rdcur;
+  unsigned live1 = tile + tstride < ntiles ? live_of(vis1) : 0u;
+  unsigned live2 = tile + 2 * tstride < ntiles ? live_of(vis2) : 0u;
+
+  // the pair after next in this wave's sequence of (tile, view) pairs, given the views of the
+  // current tile that remain after the current one (all wave-uniform): tile index 0 / 1 / 2 relative
+  // to the current tile, or -1 past the end
+  auto pair_plus2 = [&](unsigned rest, int& t2, int& v2) {
+    const unsigned rest1 = rest & (rest - 1);
+    t2 = -1, v2 = 0;
+    if (rest1) {                       // two or more views remain in this tile
+      t2 = 0, v2 = __builtin_ctz(rest1);
+    } else if (rest) {                 // one remains: then the first view of the next tile
+      if (live1) t2 = 1, v2 = __builtin_ctz(live1);
+    } else if (live1) {                // none remains: the next tile's second view, or the first of the one after
+      const unsigned l1r = live1 & (live1 - 1);
+      if (l1r) t2 = 1, v2 = __builtin_ctz(l1r);
+      else if (live2) t2 = 2, v2 = __builtin_ctz(live2);
+    }
+  };
+  unsigned par = 0;  // slot of the current pair
+  // (re)start the ring at the first view of the current tile: pair 0 -> slot 0, pair 1 -> slot 1
+  auto ring_start = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may still land in the slots
+    par = 0;
+    const int v0 = __builtin_ctz(live);
+    dma_pair(n, v0, 0);
+    const unsigned rest = live & (live - 1);
+    if (rest) dma_pair(n, __builtin_ctz(rest), 1);
+    else if (live1) dma_pair(n1, __builtin_ctz(live1), 1);
+    else dma_pair(n, v0, 1);  // no further pair: keep the op count
+  };
+  ring_start();
+
+  f4 xq[4];
 #pragma unroll
   for (int T = 0; T < 4; ++T) xq[T] = ld4(q_in + (size_t)n * C64 + 16 * T + 4 * g);
-  {
-    const int v0 = __builtin_ctz(live);
-    load_feat_row<SPL>(feat + ((size_t)n * V + v0) * C64, g, fcur);
-    rdcur = ray_diff[((size_t)n * V + v0) * 4 + g];
-  }
 
+  unsigned long long redo_lanes = 0;  // lanes (points) of the current tile to redo in the online form
+  // a point = the 4 lanes (j, g = 0..3): all of them redo if any of their channels overflowed
+  auto ovf_point = [&](bool o) {
+    unsigned b = o ? 1u : 0u;
+    b |= __shfl_xor(b, 16);
+    b |= __shfl_xor(b, 32);
+    return b != 0;
+  };
+  f2 l2e = (f2){LOG2E_F, LOG2E_F};
+  asm volatile("" : "+v"(l2e));  // keep log2(e) in registers: a literal operand blocks v_pk_fma_f32
   for (;;) {
     const bool valid = tile * 16 + j < N;
-    const long long tile_next = tile + tstride;
-    const bool has_next = tile_next < ntiles;  // wave-uniform
-    int n_next = n;
-    unsigned vis_next = vis;
-    if (has_next) point_of(tile_next, n_next, vis_next);
+    const bool has_next = tile + tstride < ntiles;  // wave-uniform
+    // points of the tile three ahead (consumed when it has become the tile two ahead)
+    const bool online = redo_lanes != 0;            // wave-uniform: second pass over this tile
+    if (!online) {
+      n3 = n2, vis3 = vis2;
+      if (tile + 3 * tstride < ntiles) point_of(tile + 3 * tstride, n3, vis3);
+    }
 
     f4 qp[4];
     {
@@ -448,118 +562,189 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
     }
     // next tile's q rows (the residual input of THIS tile is re-read at the end instead of being
     // held in 16 registers through the view loop)
-    const unsigned live_next = has_next ? live_of(vis_next) : 0u;
+    f4 xres[4];  // FOLD: the residual input stays in registers (one L1 request per 64 B saved)
     if constexpr (FOLD) {  // (the other variants have no registers to spare here: they fetch it after the loop)
 #pragma unroll
-      for (int T = 0; T < 4; ++T) xq[T] = ld4(q_in + (size_t)n_next * C64 + 16 * T + 4 * g);
+      for (int T = 0; T < 4; ++T) xres[T] = xq[T];
+#pragma unroll
+      for (int T = 0; T < 4; ++T) xq[T] = ld4(q_in + (size_t)n1 * C64 + 16 * T + 4 * g);
     }
 
     f4 mrun[4], lrun[4], acc[4];
+    // A masked view contributes exp(-1e9 - max) == 0 exactly as soon as the point has one visible
+    // view, so a (tile, view) whose 16 points are all masked-but-visible-elsewhere is skipped whole.
+    // Softmax over the views, per channel (:84-87).  It is shift invariant, so instead of a running
+    // maximum (compare / select / rescale per value) the exponentials are taken relative to the
+    // logits of the point's FIRST VISIBLE view: per value one fma, one v_exp_f32, one add, one fma.
+    // The result of a point does not depend on its tile mates (masked views add exact zeros), so
+    // any point order and any chunking give the same bits.  Three instantiations of the view loop:
+    //   HOMOG   every point of the tile sees exactly the tile's live views (the common case after
+    //           gpn_vis_order): no mask handling at all
+    //   MASKED  mixed tile: masked_fill(-1e9) and a per-lane reference
+    //   ONLINE  running-maximum form, only for points whose logits spread over more than the fp32
+    //           exponent range (> ~87 between two views): their sum overflows in the forms above,
+    //           which is detected after the loop; the tile is then run a second time in this form
+    //           and only those points are stored from it.
+    const unsigned live0 = live;
+    const int vfirst = __builtin_ctz(live0);
+    // lanes whose results this pass stores (a redo pass: the overflowed points only)
+    const bool lane_ok = valid && (!online || ((redo_lanes >> lane) & 1ull) != 0);
+    const bool homog = __all(vis == live0);
+    const int vref = vis != 0 ? __builtin_ctz(vis) : vfirst;  // MASKED: this point's reference view
 #pragma unroll
     for (int M = 0; M < 4; ++M) {
-      mrun[M] = f4_splat(-INFINITY);
+      mrun[M] = online ? f4_splat(-INFINITY) : f4_zero();  // fast forms: -log2(e) * reference logit
       lrun[M] = f4_zero();
       acc[M] = f4_zero();
     }
-    // A masked view contributes exp(-1e9 - max) == 0 exactly as soon as the point has one visible
-    // view, so a (tile, view) whose 16 points are all masked-but-visible-elsewhere is skipped whole.
-    const int v0_next = live_next ? __builtin_ctz(live_next) : 0;
 
-    while (live) {
-      const int v = __builtin_ctz(live);
-      live &= live - 1;
-      // The next LIVE view (in the last iteration: the first live view of the next tile) is fetched
-      // into the same registers as soon as this view's features have been consumed.
-      const size_t pair_next = live ? (size_t)n * V + __builtin_ctz(live) : (size_t)n_next * V + v0_next;
-      const float* fsrc = feat + pair_next * C64;
-      const float* rsrc = ray_diff + pair_next * 4 + g;
-      const float rd = rdcur;
-      rdcur = *rsrc;
-      const float mk = (vis >> v) & 1u ? 1.0f : 0.0f;
-
-      f4 vp[4], a[4];  // vp = v + pos (the value that is attended over)
+    auto view_loop = [&](auto mode_tag) {
+      constexpr int MODE = decltype(mode_tag)::value;
+      while (live) {
+        const int v = __builtin_ctz(live);
+        live &= live - 1;
+        // This pair's slot was filled by a DMA issued two iterations ago.  Younger vector-memory
+        // operations of this wave in the HOMOG form: the logits stores of the two iterations since
+        // (4 each, always issued: every lane is visible and lane 0 of a tile is a valid point) and
+        // the 5 DMA pieces of the next pair; the other forms do not count, they wait for everything.
+        if (MODE == VM_HOMOG && logits != nullptr) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VA_DMA_OPS + 8) : "memory");
+        else if (MODE == VM_HOMOG) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VA_DMA_OPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        f4 fcur[4];
+        float rd;
+        read_slot(par, fcur, rd);
+        {  // refill the slot with the pair after next (or, past the end, any valid pair: fixed op count)
+          int t2, v2;
+          pair_plus2(live, t2, v2);
+          const int nn = t2 == 1 ? n1 : (t2 == 2 ? n2 : n);
+          dma_pair(nn, t2 < 0 ? v : v2, par);
+          par ^= 1u;
+        }
+        f4 vp[4], a[4];  // vp = v + pos (the value that is attended over)
 #pragma unroll
-      for (int M = 0; M < 4; ++M) {
-        vp[M] = ld4(L.bP2 + 16 * M + 4 * g);
-        a[M] = ld4(L.bA2 + 16 * M + 4 * g);
-      }
-      // pos hidden layer: 4 -> 8 (ReLU), one fp32 MFMA
-      f4 ph = f4_relu(mfma16(p0w, rd, ld4(L.bP0 + 4 * g)));
-      if constexpr (FOLD) {
-        // v + pos = (Wv Wk) f + P2 h + b ; attn hidden = (A0 Wk) f + (A0 P2) h + aq : every product
-        // reads the split of f and h made once here
-        XS xs[3];
-        xs[0] = feat_pair(fcur[0], fcur[1]);
-        xs[1] = feat_pair(fcur[2], fcur[3]);
-        xs[2] = split8(ph, f4_zero());
-        load_feat_row<SPL>(fsrc, g, fcur);
-        lin_Sx<4, 4>(L.Wv, xs, vp, lane);
-        lin_Sx<1, 4>(L.P2, xs + 2, vp, lane);
-        f4 ah = aq;
-        lin_Sx<6, 1>(L.AF, xs, &ah, lane);
-        ah = f4_relu(ah);
-        lin<SPL, 1, 4>(L.A2, VA_LD8, &ah, a, lane);
-      } else {
-        f4 k[4];
-#pragma unroll
-        for (int M = 0; M < 4; ++M) k[M] = f4_zero();
-        if constexpr (SPL) {
-          const XS xf[2] = {feat_pair(fcur[0], fcur[1]), feat_pair(fcur[2], fcur[3])};
-          lin_Sx<4, 4>(L.Wk, xf, k, lane);
+        for (int M = 0; M < 4; ++M) {
+          vp[M] = ld4(L.bP2 + 16 * M + 4 * g);
+          a[M] = ld4(L.bA2 + 16 * M + 4 * g);
+        }
+        // pos hidden layer: 4 -> 8 (ReLU), one fp32 MFMA
+        f4 ph = f4_relu(mfma16(p0w, rd, ld4(L.bP0 + 4 * g)));
+        if constexpr (FOLD) {
+          // v + pos = (Wv Wk) f + P2 h + b ; attn hidden = (A0 Wk) f + (A0 P2) h + aq : every product
+          // reads the split of f and h made once here
+          XS xs[3];
+          xs[0] = feat_pair(fcur[0], fcur[1]);
+          xs[1] = feat_pair(fcur[2], fcur[3]);
+          xs[2] = split8(ph, f4_zero());
+          lin_Sx<4, 4>(L.Wv, xs, vp, lane);
+          lin_Sx<1, 4>(L.P2, xs + 2, vp, lane);
+          f4 ah = aq;
+          lin_Sx<6, 1>(L.AF, xs, &ah, lane);
+          ah = f4_relu(ah);
+          lin<SPL, 1, 4>(L.A2, VA_LD8, &ah, a, lane);
         } else {
-          lin_T<4, 4>(L.Wk, LDW, fcur, k, lane);   // k = k_fc(feat)
+          f4 k[4];
+#pragma unroll
+          for (int M = 0; M < 4; ++M) k[M] = f4_zero();
+          if constexpr (SPL) {
+            const XS xf[2] = {feat_pair(fcur[0], fcur[1]), feat_pair(fcur[2], fcur[3])};
+            lin_Sx<4, 4>(L.Wk, xf, k, lane);
+          } else {
+            lin_T<4, 4>(L.Wk, LDW, fcur, k, lane);   // k = k_fc(feat)
+          }
+          f4 pos[4];
+#pragma unroll
+          for (int M = 0; M < 4; ++M) pos[M] = vp[M];
+          lin<SPL, 1, 4>(L.P2, VA_LD8, &ph, pos, lane);  // pos = pos_fc(ray_diff): 4 -> 8 -> 64
+          // attn = attn_fc(k - q + pos): 64 -> 8 (ReLU) -> 64
+          f4 ain[4];
+#pragma unroll
+          for (int M = 0; M < 4; ++M) ain[M] = k[M] - qp[M] + pos[M];
+#pragma unroll
+          for (int M = 0; M < 4; ++M) vp[M] = f4_zero();
+          lin<SPL, 4, 4>(L.Wv, LDW, k, vp, lane);     // v = v_fc(k)   (reference quirk, :77)
+#pragma unroll
+          for (int M = 0; M < 4; ++M) vp[M] = vp[M] + pos[M];
+          f4 ah = ld4(L.bA0 + 4 * g);
+          lin<SPL, 4, 1>(L.A0, LDW, ain, &ah, lane);
+          ah = f4_relu(ah);
+          lin<SPL, 1, 4>(L.A2, VA_LD8, &ah, a, lane);
         }
-        load_feat_row<SPL>(fsrc, g, fcur);
-        f4 pos[4];
+const bool vis_v = MODE == VM_HOMOG || ((vis >> v) & 1u) != 0;
+        if (logits != nullptr && lane_ok && vis_v) {  // masked pairs are never read back
+          float* lo = logits + ((size_t)n * V + v) * logits_ld + 4 * g;
 #pragma unroll
-        for (int M = 0; M < 4; ++M) pos[M] = vp[M];
-        lin<SPL, 1, 4>(L.P2, VA_LD8, &ph, pos, lane);  // pos = pos_fc(ray_diff): 4 -> 8 -> 64
-        // attn = attn_fc(k - q + pos): 64 -> 8 (ReLU) -> 64
-        f4 ain[4];
+          for (int M = 0; M < 4; ++M) st4(lo + 16 * M, a[M]);
+        }
+        if constexpr (MODE != VM_HOMOG) {
+          if (!vis_v) {
 #pragma unroll
-        for (int M = 0; M < 4; ++M) ain[M] = k[M] - qp[M] + pos[M];
+            for (int M = 0; M < 4; ++M) a[M] = f4_splat(-1e9f);  // masked_fill (:83)
+          }
+        }
+        if constexpr (MODE == VM_HOMOG) {
+          if (v == vfirst) {
 #pragma unroll
-        for (int M = 0; M < 4; ++M) vp[M] = f4_zero();
-        lin<SPL, 4, 4>(L.Wv, LDW, k, vp, lane);     // v = v_fc(k)   (reference quirk, :77)
+            for (int M = 0; M < 4; ++M) mrun[M] = a[M] * f4_splat(-LOG2E_F);
+          }
+        } else if constexpr (MODE == VM_MASKED) {
+          if (v == vref) {
 #pragma unroll
-        for (int M = 0; M < 4; ++M) vp[M] = vp[M] + pos[M];
-        f4 ah = ld4(L.bA0 + 4 * g);
-        lin<SPL, 4, 1>(L.A0, LDW, ain, &ah, lane);
-        ah = f4_relu(ah);
-        lin<SPL, 1, 4>(L.A2, VA_LD8, &ah, a, lane);
-      }
-      if (__any(mk == 0.0f)) {  // tiles are visibility-homogeneous: usually no lane is masked here
-        if (mk == 0.0f) {
+            for (int M = 0; M < 4; ++M) mrun[M] = a[M] * f4_splat(-LOG2E_F);
+          }
+        }
+        if constexpr (MODE != VM_ONLINE) {
 #pragma unroll
-          for (int M = 0; M < 4; ++M) a[M] = f4_splat(-1e9f);  // masked_fill (:83)
+          for (int M = 0; M < 4; ++M) {
+            f4 d, p;
+            d.lo = a[M].lo * l2e + mrun[M].lo;
+            d.hi = a[M].hi * l2e + mrun[M].hi;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(d[r]);
+            lrun[M] = lrun[M] + p;
+            acc[M] = acc[M] + vp[M] * p;
+          }
+        } else {
+          // one of the two rescale factors is always exp(0) = 1, so a single exponential of
+          // -|a - max| serves both
+#pragma unroll
+          for (int M = 0; M < 4; ++M)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float d = a[M][r] - mrun[M][r];
+              const float e = __expf(-fabsf(d));
+              const bool up = d > 0.0f;  // new maximum
+              const float alpha = up ? e : 1.0f, p = up ? 1.0f : e;
+              lrun[M][r] = lrun[M][r] * alpha + p;
+              acc[M][r] = acc[M][r] * alpha + vp[M][r] * p;
+              mrun[M][r] = up ? a[M][r] : mrun[M][r];
+            }
         }
       }
-      if (logits != nullptr && valid && mk != 0.0f) {  // masked pairs are never read back
-        float* lo = logits + ((size_t)n * V + v) * logits_ld + 4 * g;
+    };
+    bool store_ok = valid;
+    unsigned long long redo_next = 0;
+    if (online) {
+      view_loop(std::integral_constant<int, VM_ONLINE>{});
+      store_ok = lane_ok;
+    } else {
+      if (homog) view_loop(std::integral_constant<int, VM_HOMOG>{});
+      else view_loop(std::integral_constant<int, VM_MASKED>{});
+      float lm = 0.f;
 #pragma unroll
-        for (int M = 0; M < 4; ++M) st4(lo + 16 * M, a[M]);
-      }
-      // online softmax over views, per channel (:84-87).  One of the two rescale factors is always
-      // exp(0) = 1, so a single exponential of -|a - max| serves both.
-#pragma unroll
-      for (int M = 0; M < 4; ++M)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float d = a[M][r] - mrun[M][r];
-          const float e = __expf(-fabsf(d));
-          const bool up = d > 0.0f;  // new maximum
-          const float alpha = up ? e : 1.0f, p = up ? 1.0f : e;
-          lrun[M][r] = lrun[M][r] * alpha + p;
-          acc[M][r] = acc[M][r] * alpha + vp[M][r] * p;
-          mrun[M][r] = up ? a[M][r] : mrun[M][r];
-        }
+      for (int M = 0; M < 4; ++M) lm = max3_nc(lm, max_nc(lrun[M].x, lrun[M].y), max_nc(lrun[M].z, lrun[M].w));
+      const bool ovf = !(lm < 1e30f);  // some channel's sum overflowed (or is NaN)
+      redo_next = __ballot(ovf_point(ovf));
+      store_ok = valid && ((redo_next >> lane) & 1ull) == 0;
     }
     f4 xr[4], xs[4], y[4], rl[4];
 #pragma unroll
-    for (int T = 0; T < 4; ++T) xr[T] = ld4(q_in + (size_t)n * C64 + 16 * T + 4 * g);  // residual input
+    for (int T = 0; T < 4; ++T) {
+      if constexpr (FOLD) xr[T] = xres[T];
+      else xr[T] = ld4(q_in + (size_t)n * C64 + 16 * T + 4 * g);  // residual input
+    }
     if constexpr (!FOLD) {
 #pragma unroll
-      for (int T = 0; T < 4; ++T) xq[T] = ld4(q_in + (size_t)n_next * C64 + 16 * T + 4 * g);
+      for (int T = 0; T < 4; ++T) xq[T] = ld4(q_in + (size_t)n1 * C64 + 16 * T + 4 * g);
     }
 #pragma unroll
     for (int M = 0; M < 4; ++M) {
@@ -569,25 +754,42 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
       y[M] = ld4(L.bO + 16 * M + 4 * g);
     }
     lin<SPL, 4, 4>(L.Wo, LDW, xs, y, lane);
-    if (valid) {
+    if (store_ok) {
 #pragma unroll
       for (int M = 0; M < 4; ++M) st4(q_out + (size_t)n * C64 + 16 * M + 4 * g, y[M] + xr[M]);
       if (stats != nullptr) {  // log-sum-exp over the views: softmax weight = exp(logit - lse)
 #pragma unroll
         for (int M = 0; M < 4; ++M) {
-          f4 lse;
+          f4 lse;  // the sum is >= 1 in both forms: bare v_log_f32 (log2), no denormal handling
 #pragma unroll
-          for (int r = 0; r < 4; ++r) lse[r] = mrun[M][r] + __logf(lrun[M][r]);
+          for (int r = 0; r < 4; ++r) {
+            const float l2 = __builtin_amdgcn_logf(lrun[M][r]);
+            lse[r] = online ? mrun[M][r] + l2 * LN2_F : (l2 - mrun[M][r]) * LN2_F;
+          }
           st4(stats + (size_t)n * stats_ld + 16 * M + 4 * g, lse);
         }
       }
     }
+    if (redo_next != 0) {
+      // run this tile again in the online form for the overflowed points.  Their rows of q_in are
+      // untouched (nothing of theirs has been stored); the other lanes recompute from whatever is
+      // there now and are not stored.
+      redo_lanes = redo_next;
+      live = live0;
+#pragma unroll
+      for (int T = 0; T < 4; ++T) xq[T] = ld4(q_in + (size_t)n * C64 + 16 * T + 4 * g);
+      ring_start();
+      continue;
+    }
+    redo_lanes = 0;
     if (!has_next) break;
-    tile = tile_next;
-    n = n_next;
-    vis = vis_next;
-    live = live_next;
+    tile += tstride;
+    n = n1, vis = vis1, live = live1;
+    n1 = n2, vis1 = vis2, live1 = live2;
+    n2 = n3, vis2 = vis3;
+    live2 = tile + 2 * tstride < ntiles ? live_of(vis2) : 0u;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last (unused) ring fills land before the wave ends
 }
 
 // ------------------------------------------------------------------------------------ feed-forward
@@ -1340,7 +1542,7 @@ extern "C" int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const
               "gpn_view_attn: stats_ld must be a multiple of 4 and >= %d (got %d)", C64, stats_ld);
   const bool spl = gpn_precision() == GPN_PREC_BF16X3;
   const bool fold = spl && L->folded != nullptr;
-  const size_t lds = sizeof(float) * view_lds_floats(spl);
+  const size_t lds = sizeof(float) * view_lds_floats(spl) + (VA_TPB / 64) * 2 * VA_SLOT_BYTES;
   const void* fn = fold ? reinterpret_cast<const void*>(k_view_attn<true, true>)
                         : spl ? reinterpret_cast<const void*>(k_view_attn<true, false>)
                               : reinterpret_cast<const void*>(k_view_attn<false, false>);

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -39,6 +40,11 @@ __device__ __forceinline__ f4 f4_max(f4 a, f4 b) {
 }
 __device__ __forceinline__ f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
 __device__ __forceinline__ void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
+#ifdef GPN_NO_NT
+__device__ __forceinline__ void st4_nt(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
+#else
+__device__ __forceinline__ void st4_nt(float* p, f4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f4*>(p)); }
+#endif
 
 // y[M] += W[16M.., 16T..] . x[T]   (transposed orientation: x, y are T-tiles; W row-major in LDS with
 // leading dimension ldw floats).  y must be initialised (bias or zero) by the caller.

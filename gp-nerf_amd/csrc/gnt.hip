@@ -467,8 +467,8 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
   int rb_off[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    // split mode: f[2P + hm] = unit (h = P, c = 2g + hm); fp32 mode: f[T] = (h = T>>1, c = 4(T&1) + g)
-    const int h = k >> 1, c = SPL ? 2 * g + (k & 1) : 4 * (k & 1) + g;
+    // split mode: f[2P + hm] = unit (line P, piece 4 hm + g); fp32 mode: f[T] = (line T>>1, piece 4(T&1) + g)
+    const int h = k >> 1, c = 4 * (k & 1) + g;
     rb_off[k] = (2 * h + (j >> 3)) * 1024 + ((j & 7) * 8 + ((c + sj) & 7)) * 16;
   }
   auto read_slot = [&](unsigned sl, f4* f, float& rd_) {

@@ -149,7 +149,7 @@ int gpn_posenc(const float* pts, const float* ray_d, int R, int S, float* emb, g
  * rgb_feat [N,V,3+F] -> feat [N,V,C], q0 [N,C].
  * `feat` is the tensor gpn_view_attn reads.  In GPN_PREC_FP32 mode it is plain fp32.  In
  * GPN_PREC_BF16X3 mode every row of C = 64 channels is stored in the operand format of that mode (same
- * 256 bytes): 16 units of 8 bf16, unit ((P*4 + g)*2 + hm), P < 2, g < 4, holding the high (hm = 0)
+ * 256 bytes): 16 units of 8 bf16, unit ((P*2 + hm)*4 + g), P < 2, g < 4, holding the high (hm = 0)
  * or the residual (hm = 1) bf16 piece of channels {32P+4g+r, 32P+16+4g+r : r < 4}; value = hi + mid.
  * Both calls must run in the same mode. */
 int gpn_rgbfeat(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* rgb_feat, int N,

@@ -62,7 +62,8 @@ def enc_feat(x, prec):
     t = t.reshape(lead + (2, 4, 8))
     hi = t.bfloat16()
     mid = (t - hi.float()).bfloat16()
-    return torch.stack([hi, mid], dim=-2).contiguous().view(torch.float32).reshape(lead + (64,))
+    # unit ((P*2 + hm)*4 + g): [..., P, hm, g, 8]
+    return torch.stack([hi, mid], dim=-3).contiguous().view(torch.float32).reshape(lead + (64,))
 
 
 def dec_feat(buf, prec):
@@ -70,7 +71,7 @@ def dec_feat(buf, prec):
     if prec != "bf16x3":
         return buf
     lead = buf.shape[:-1]
-    t = buf.contiguous().view(torch.bfloat16).reshape(lead + (2, 4, 2, 8)).float().sum(dim=-2)  # [..., P, g, 8]
+    t = buf.contiguous().view(torch.bfloat16).reshape(lead + (2, 2, 4, 8)).float().sum(dim=-3)  # [..., P, g, 8]
     t = t.reshape(lead + (2, 4, 2, 4)).permute(*range(len(lead)), -4, -2, -3, -1)  # [..., P, half, g, r]
     return t.reshape(lead + (64,))
 

@@ -18,10 +18,11 @@ as three bf16 MFMAs on split operands with fp32 accumulation (include/gpnerf_hip
 same 1e-4 parity bar as the exact-fp32 mode (tests/test_gpu_parity.py runs both).  The exact mode
 (fp32 MFMA, reference operation order) is timed too and reported under "fp32_exact".
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_view_attn): algorithmic
-flops per launch (the reference algorithm's GEMM flops, whether or not the kernel
-executes them) / mean launch duration measured with HIP events inside the timed steps, against
-the MFMA peak of the mode.  `cpu_baseline` is the CPU oracle (a port of the reference path) on a
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_view_attn), which is
+HBM-bound: algorithmic bytes per launch / mean launch duration measured with HIP events inside the
+timed steps, against the 8 TB/s HBM peak; `traffic` = measured HBM bytes per launch (PMC passes,
+profiles/); `roofline.mfma` carries the same launch against the MFMA peak of the mode (SURVEY.md 8(d)
+reference-algorithm GEMM flops).  `cpu_baseline` is the CPU oracle (a port of the reference path) on a
 bounded ray sample.
 """
 import argparse
@@ -41,6 +42,9 @@ N_SAMPLES, N_IMPORTANCE, VIEWS = 48, 16, 10
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
 BF16_MATRIX_PEAK_TFLOPS = 2500.0  # dense; a bf16x3 product costs three MFMA flops per algorithmic flop
 HBM_PEAK_GBPS = 8000.0
+# what a bare copy kernel reaches on this GPU for k_view_attn's access shape (random 256-byte rows,
+# read + written; tools/micro/reqbench.hip, profiles/r01_reqbench.txt); sequential read-only: 6250
+RANDOM_ROW_RW_CEILING_GBPS = 4700.0
 
 
 def view_attn_flops_per_point(V):
@@ -223,34 +227,42 @@ def main():
 
     ret, elapsed, tm = timed(a.precision, a.steps, a.warmup)
 
-    # dominant kernel: k_view_attn, 8 launches on N=4096*48 points + 8 on N=4096*64 per step
+    # dominant kernel: k_view_attn, 8 launches on N=4096*48 points + 8 on N=4096*64 per step.
+    # It is HBM-bound (62 % of the 8 TB/s peak in measured traffic, at the
+    # ceiling a bare copy kernel reaches for the same access shape -- random 256-byte rows read and
+    # written -- while the MFMA pipe is < 20 % busy), so the roofline is the HBM one:
+    # achieved = ALGORITHMIC bytes per launch / mean launch time.
     launches = tm.launches["view_attn"]
     mean_ms = tm.ms["view_attn"] / max(1, launches)
     pts_per_launch = CHUNK * (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) / 2.0
+    vstat = visibility_stats(scene, rb, ret, projector)
+    live = vstat["computed_pair_fraction"]
+    # per computed (point, view) pair: feature row 256 B + ray_diff 16 B; per visible pair: logits
+    # row 256 B; per point: q in 256 + q out 256 + softmax stats 256 + order/visibility words 8
+    alg_bytes = (VIEWS * live * (256 + 16) + VIEWS * vstat["visible_pair_fraction"] * 256 +
+                 256 + 256 + 256 + 8) * pts_per_launch
+    achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
+    traffic = pmc_traffic("k_view_attn")
+    roofline = {"bound": "hbm", "kernel": "k_view_attn", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "launches": launches, "mean_launch_ms": mean_ms,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "traffic_GBps": (traffic / (mean_ms * 1e-3) / 1e9) if traffic else None,
+                "access_shape_ceiling_GBps": RANDOM_ROW_RW_CEILING_GBPS,
+                "visibility": vstat}
+    # the same launch against the MFMA roofline (reference-algorithm GEMM flops, whether or not the
+    # kernel executes them; executed flops alongside)
     flops_per_launch = view_attn_flops_per_point(VIEWS) * pts_per_launch
-    achieved = flops_per_launch / (mean_ms * 1e-3) / 1e12
     if a.precision == "bf16x3":
         peak, peak_note = BF16_MATRIX_PEAK_TFLOPS / 3.0, "dense bf16 MFMA peak / 3 (three bf16 MFMAs per product)"
     else:
         peak, peak_note = FP32_MATRIX_PEAK_TFLOPS, "fp32 MFMA peak"
-    vstat = visibility_stats(scene, rb, ret, projector) if rank == 0 else None
-    roofline = {"bound": "mfma", "kernel": "k_view_attn", "achieved": achieved, "peak": peak,
-                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": pmc_traffic("k_view_attn"),
-                "peak_note": peak_note, "launches": launches, "mean_launch_ms": mean_ms,
-                "flops_per_launch": flops_per_launch}
-    if vstat is not None:
-        # what the kernel really executes / moves (dead views skipped, folded weights): see DESIGN.md
-        live = vstat["computed_pair_fraction"]
-        ex_flops = (VIEWS * live * VIEW_EXEC_FLOPS_PER_PAIR[a.precision] +
-                    VIEW_EXEC_FLOPS_PER_POINT[a.precision]) * pts_per_launch
-        alg_bytes = (VIEWS * live * (256 + 16) + VIEWS * vstat["visible_pair_fraction"] * 256 +
-                     256 + 256 + 256 + 8) * pts_per_launch
-        roofline.update({
-            "executed_mfma_tflops": ex_flops / (mean_ms * 1e-3) / 1e12,
-            "algorithmic_bytes_per_launch": alg_bytes,
-            "hbm_achieved_GBps": alg_bytes / (mean_ms * 1e-3) / 1e9,
-            "hbm_frac": alg_bytes / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "visibility": vstat})
+    ex_flops = (VIEWS * live * VIEW_EXEC_FLOPS_PER_PAIR[a.precision] +
+                VIEW_EXEC_FLOPS_PER_POINT[a.precision]) * pts_per_launch
+    roofline["mfma"] = {"achieved_TFLOPs": flops_per_launch / (mean_ms * 1e-3) / 1e12, "peak_TFLOPs": peak,
+                        "frac": flops_per_launch / (mean_ms * 1e-3) / 1e12 / peak, "peak_note": peak_note,
+                        "flops_per_launch": flops_per_launch,
+                        "executed_mfma_TFLOPs": ex_flops / (mean_ms * 1e-3) / 1e12}
 
     if True:  # the other arithmetic mode on the same workload (shorter run; every rank takes part)
         omode = "fp32" if a.precision == "bf16x3" else "bf16x3"

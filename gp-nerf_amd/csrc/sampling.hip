@@ -2,6 +2,7 @@
 //   gpn_sample_along_ray : reference gpnerf/render_ray.py:58-102
 //   gpn_sample_fine      : reference gpnerf/render_ray.py:162-191 + :9-55
 //   gpn_raw2outputs      : reference gpnerf/render_ray.py:110-159
+//   gpn_rays_single_image: reference gpnerf/sample_ray.py:108-132
 // Built with -ffp-contract=off: every mul/add below is rounded separately, in the order the
 // reference's elementwise torch ops apply them.
 #include "common.h"
@@ -243,5 +244,55 @@ extern "C" int gpn_raw2outputs(const float* raw, const float* z_vals, const floa
   hipLaunchKernelGGL(k_raw2outputs, dim3(gpn_ceil_div(R, 128)), dim3(128), 0, (hipStream_t)stream,
                      raw, z_vals, vis_mask, R, S, white_bkgd, rgb, depth, weights, alpha, ray_mask);
   GPN_LAUNCH_CHECK("k_raw2outputs");
+  return GPN_OK;
+}
+
+// ------------------------------------------------------------------------------------ ray generation
+// RaySamplerSingleImage.get_rays_single_image (reference sample_ray.py:108-132): pixel (u, v) of the
+// strided grid -> d = M . [u, v, 1] with M = c2w[:3,:3] . K[:3,:3]^-1 (3x3, computed by the caller
+// with the reference's own torch ops), o = c2w[:3,3].  torch's CPU bmm evaluates each output as the
+// k-ascending chain  M[r][0]*u, fma(M[r][1], v, .), fma(M[r][2], 1, .)  (verified bit for bit on
+// 76,800 rays), which is what the kernel does; optional `inds` picks pixels of the strided grid
+// (random_sample, :172-214) instead of enumerating all of them.
+struct GpnRayGenArgs {
+  float m[9];
+  float o[3];
+};
+
+__global__ void k_rays_single_image(GpnRayGenArgs a, int Ws, int stride, long long n,
+                                    const long long* __restrict__ inds, float* __restrict__ rays_o,
+                                    float* __restrict__ rays_d) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long p = inds ? inds[i] : i;
+  const float u = (float)((int)(p % Ws) * stride), v = (float)((int)(p / Ws) * stride);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    float acc = a.m[3 * r] * u;
+    acc = __fmaf_rn(a.m[3 * r + 1], v, acc);
+    acc = __fmaf_rn(a.m[3 * r + 2], 1.0f, acc);
+    rays_d[i * 3 + r] = acc;
+    rays_o[i * 3 + r] = a.o[r];
+  }
+}
+
+extern "C" int gpn_rays_single_image(const float* M, const float* origin, int H, int W, int stride,
+                                     const long long* inds, long long n_inds, float* rays_o,
+                                     float* rays_d, gpn_stream_t stream) {
+  GPN_REQUIRE(M && origin, "gpn_rays_single_image: null matrix / origin (host pointers)");
+  GPN_REQUIRE(H >= 1 && W >= 1 && stride >= 1, "gpn_rays_single_image: bad image size %dx%d stride %d",
+              H, W, stride);
+  const int Hs = (H + stride - 1) / stride, Ws = (W + stride - 1) / stride;
+  const long long n = inds ? n_inds : (long long)Hs * Ws;
+  GPN_REQUIRE(n >= 0, "gpn_rays_single_image: negative count");
+  if (n == 0) return GPN_OK;
+  GPN_REQUIRE(rays_o && rays_d, "gpn_rays_single_image: null output");
+  GpnRayGenArgs a;
+  for (int i = 0; i < 9; ++i) a.m[i] = M[i];
+  for (int i = 0; i < 3; ++i) a.o[i] = origin[i];
+  GpnStageTimer timer(GPN_ST_SAMPLE, (hipStream_t)stream);
+  hipLaunchKernelGGL(k_rays_single_image, dim3(gpn_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     a, Ws, stride, n, inds, rays_o, rays_d);
+  GPN_LAUNCH_CHECK("k_rays_single_image");
   return GPN_OK;
 }

@@ -1,0 +1,183 @@
+"""`RaySamplerSingleImage` -- same constructor, attributes and return dictionaries as reference
+gpnerf/sample_ray.py:38-214 (the step right before the hot path).
+
+The reference builds all rays of the image in numpy on the host and copies 24 bytes per ray to the
+GPU for every image (get_all :134-147).  Here the rays are GENERATED on the device by
+`gpn_rays_single_image` (csrc/sampling.hip) from the 3x3 matrix c2w[:3,:3] . K[:3,:3]^-1 and the
+camera centre, bit for bit the reference's values; nothing but 12 floats crosses PCIe.  The
+per-image tensors that only ride along (rgb, labels, depth, source views) are moved with `.to()`.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+rng = np.random.RandomState(234)  # reference sample_ray.py:6 (module-level, same seed)
+
+
+def parse_camera(params):
+    """23-float cameras (reference :13-18)."""
+    H = params[:, 0]
+    W = params[:, 1]
+    intrinsics = params[:, 2:11].reshape((-1, 3, 3))
+    c2w = params[:, 11:23].reshape((-1, 3, 4))
+    return W, H, intrinsics, c2w
+
+
+def parse_camera_ray(params):
+    """34-float cameras [H, W, K(4x4), c2w(4x4)] (reference :20-25)."""
+    H = params[:, 0]
+    W = params[:, 1]
+    intrinsics = params[:, 2:18].reshape((-1, 4, 4))
+    c2w = params[:, 18:34].reshape((-1, 4, 4))
+    return W, H, intrinsics, c2w
+
+
+def _dev(t, device):
+    return t.to(device) if t is not None else None
+
+
+class RaySamplerSingleImage(object):
+    def __init__(self, data, device, resize_factor=1, render_stride=1):
+        super().__init__()
+        self.render_stride = render_stride
+        self.rgb = data["rgb"] if "rgb" in data.keys() else None
+        self.labels = data["labels"] if "labels" in data.keys() else None
+        self.camera = data["camera"]
+        self.rgb_path = data["rgb_path"]
+        self.true_depth = data["true_depth"]
+        self.depth_mask = data["depth_mask"]
+        self.depth_range = data["depth_range"]
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("RaySamplerSingleImage generates rays on a HIP device (got %s); there "
+                               "is no CPU fallback" % (self.device,))
+        if self.camera.shape[-1] == 34:
+            W, H, self.intrinsics, self.c2w_mat = parse_camera_ray(self.camera)
+        else:
+            W, H, self.intrinsics, self.c2w_mat = parse_camera(self.camera)
+        self.batch_size = len(self.camera)
+        if self.batch_size != 1:
+            raise ValueError("one query image per sampler (the render path asserts batch size 1, "
+                             "reference projection.py:97-101)")
+
+        self.H = int(H[0])
+        self.W = int(W[0])
+
+        # half-resolution output (reference :58-80)
+        if resize_factor != 1:
+            self.W = int(self.W * resize_factor)
+            self.H = int(self.H * resize_factor)
+            self.intrinsics = self.intrinsics.clone()
+            self.intrinsics[:, :2, :3] *= resize_factor
+            for name in ("rgb", "labels", "true_depth", "depth_mask"):
+                t = getattr(self, name)
+                if t is not None:
+                    setattr(self, name, F.interpolate(t.permute(0, 3, 1, 2),
+                                                      scale_factor=resize_factor).permute(0, 2, 3, 1))
+
+        self.rays_o, self.rays_d = self.get_rays_single_image(self.H, self.W, self.intrinsics,
+                                                              self.c2w_mat)
+        if self.rgb is not None:
+            self.rgb = self.rgb.reshape(-1, 3)
+        if self.labels is not None:
+            self.labels = self.labels.reshape(-1, 1)
+        if self.true_depth is not None:
+            self.true_depth = self.true_depth.reshape(-1, 1)
+        if self.depth_mask is not None:
+            self.depth_mask = self.depth_mask.reshape(-1, 1)
+
+        self.src_rgbs = data["src_rgbs"] if "src_rgbs" in data.keys() else None
+        self.src_cameras = data["src_cameras"] if "src_cameras" in data.keys() else None
+        self.src_labels = data["src_labels"] if "src_labels" in data.keys() else None
+
+    # -------------------------------------------------------------------------------------------
+    def _matrix(self, intrinsics, c2w):
+        """M = c2w[:3,:3] . K[:3,:3]^-1 and o = c2w[:3,3] with the reference's own CPU ops (:124-130)."""
+        intr = intrinsics.detach().float().cpu()
+        c2w = c2w.detach().float().cpu()
+        M = c2w[:, :3, :3].bmm(torch.inverse(intr[:, :3, :3]))[0].contiguous()
+        o = c2w[0, :3, 3].contiguous()
+        return M, o
+
+    def _generate(self, H, W, intrinsics, c2w, inds=None):
+        M, o = self._matrix(intrinsics, c2w)
+        stride = self.render_stride
+        if inds is None:
+            n = len(range(0, H, stride)) * len(range(0, W, stride))
+            ip, ni = None, 0
+        else:
+            inds = torch.as_tensor(inds, dtype=torch.int64, device=self.device).contiguous()
+            n, ip, ni = inds.numel(), C.c_void_p(inds.data_ptr()), inds.numel()
+        rays_o = torch.empty((n, 3), device=self.device)
+        rays_d = torch.empty((n, 3), device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().gpn_rays_single_image(
+                C.c_void_p(M.data_ptr()), C.c_void_p(o.data_ptr()), H, W, stride, ip, ni,
+                _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.stream()), "gpn_rays_single_image")
+        return rays_o, rays_d
+
+    def get_rays_single_image(self, H, W, intrinsics, c2w):
+        """reference :108-132 -> (rays_o, rays_d) [H'*W', 3], on the device."""
+        return self._generate(H, W, intrinsics, c2w)
+
+    def get_all(self):
+        """reference :134-147 (every entry on the device; rays are already there)."""
+        d = self.device
+        return {
+            "ray_o": self.rays_o,
+            "ray_d": self.rays_d,
+            "depth_range": _dev(self.depth_range, d),
+            "camera": _dev(self.camera, d),
+            "true_depth": _dev(self.true_depth, d),
+            "rgb": _dev(self.rgb, d),
+            "src_rgbs": _dev(self.src_rgbs, d),
+            "labels": _dev(self.labels, d),
+            "src_labels": _dev(self.src_labels, d),
+            "src_cameras": _dev(self.src_cameras, d),
+        }
+
+    def sample_random_pixel(self, N_rand, sample_mode, center_ratio=0.8):
+        """reference :149-170 (host-side index choice with the module's RandomState)."""
+        if sample_mode == "center":
+            border_H = int(self.H * (1 - center_ratio) / 2.0)
+            border_W = int(self.W * (1 - center_ratio) / 2.0)
+            u, v = np.meshgrid(np.arange(border_H, self.H - border_H),
+                               np.arange(border_W, self.W - border_W))
+            u = u.reshape(-1)
+            v = v.reshape(-1)
+            select_inds = rng.choice(u.shape[0], size=(N_rand,), replace=False)
+            select_inds = v[select_inds] + self.W * u[select_inds]
+        elif sample_mode == "uniform":
+            select_inds = rng.choice(self.H * self.W, size=(N_rand,), replace=False)
+        else:
+            raise Exception("unknown sample mode!")
+        return select_inds
+
+    def random_sample(self, N_rand, sample_mode, center_ratio=0.8):
+        """reference :172-214: N_rand rays of the image (indices chosen on the host as in the
+        reference, the rays themselves gathered on the device)."""
+        select_inds = self.sample_random_pixel(N_rand, sample_mode, center_ratio)
+        idx = torch.as_tensor(select_inds, dtype=torch.int64, device=self.device)
+        d = self.device
+
+        def pick(t):
+            return _dev(t, d)[idx] if t is not None else None
+
+        return {
+            "ray_o": self.rays_o[idx],
+            "ray_d": self.rays_d[idx],
+            "camera": _dev(self.camera, d),
+            "depth_range": _dev(self.depth_range, d),
+            "rgb": pick(self.rgb),
+            "true_depth": pick(self.true_depth),
+            "depth_mask": pick(self.depth_mask) if self.true_depth is not None else None,
+            "src_rgbs": _dev(self.src_rgbs, d),
+            "labels": pick(self.labels),
+            "src_labels": _dev(self.src_labels, d),
+            "src_cameras": _dev(self.src_cameras, d),
+            "selected_inds": select_inds,
+        }

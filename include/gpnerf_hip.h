@@ -69,6 +69,17 @@ int gpn_raw2outputs(const float* raw, const float* z_vals, const float* vis_mask
                     int white_bkgd, float* rgb, float* depth, float* weights, float* alpha,
                     float* ray_mask, gpn_stream_t stream);
 
+/* RaySamplerSingleImage.get_rays_single_image, reference gpnerf/sample_ray.py:108-132 (and the
+ * pixel selection of random_sample, :172-214): rays of the strided pixel grid of an H x W image,
+ * generated on the device instead of built on the host and copied.  M [9] = c2w[:3,:3] . K[:3,:3]^-1
+ * (row-major) and origin [3] = c2w[:3,3] are HOST pointers (computed once per image with the
+ * reference's own torch ops).  inds == NULL: all ceil(H/stride) x ceil(W/stride) pixels, row-major
+ * (u = stride*col, v = stride*row); otherwise n_inds flat indices (int64, device) into that grid.
+ * rays_o, rays_d [n,3].  Bit-exact with the reference's CPU result. */
+int gpn_rays_single_image(const float* M, const float* origin, int H, int W, int stride,
+                          const long long* inds, long long n_inds, float* rays_o, float* rays_d,
+                          gpn_stream_t stream);
+
 /* ------------------------------------------------------------------ projector (subsystem 1) */
 
 /* NCHW -> NHWC repack of a source-view map stack (done once per image; the reference samples NCHW

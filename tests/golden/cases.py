@@ -102,3 +102,21 @@ def g5_render_image():
     sc = _small_scene(24, 32, 4, seed=31337, rig=dict(dx=0.1, dy=0.02, yaw_deg=-2.0))
     return dict(ray_batch=sc.ray_batch(), featmaps=sc.featmaps, deep_semantics=sc.deep_semantics,
                 H=24, W=32)
+
+
+def g6_sample_ray():
+    """Two RaySamplerSingleImage inputs (reference sample_ray.py:38): a small ScanNet-shaped image with a
+    yawed, translated camera at stride 1, and a Replica-shaped 480x640 image at stride 2."""
+    out = {}
+    for tag, (H, W, K, stride, i) in {"small": (48, 64, synth.scaled_intrinsics(synth.SCANNET_K, 0.2, 0.2), 1, 3),
+                                      "replica": (480, 640, synth.REPLICA_K, 2, 7)}.items():
+        cam = torch.from_numpy(synth.source_rig(10, H, W, K, dx=0.21, dy=0.07, yaw_deg=-3.5)[i])[None]
+        out[tag] = dict(camera=cam, rgb=torch.from_numpy(synth.hash_uniform(77, 5, (1, H, W, 3))),
+                        depth_range=torch.tensor([[0.1, 6.0]]), stride=torch.tensor(stride))
+    return out
+
+
+def g6_data(c):
+    """The `data` dict RaySamplerSingleImage reads (keys of reference sample_ray.py:41-48)."""
+    return {"rgb": c["rgb"], "camera": c["camera"], "rgb_path": "synthetic", "true_depth": None,
+            "depth_mask": None, "depth_range": c["depth_range"]}

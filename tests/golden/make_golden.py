@@ -52,7 +52,29 @@ def save(name, **arrays):
 
 
 @torch.no_grad()
+def g6():
+    """G6: the reference's own RaySamplerSingleImage (sample_ray.py:38-147), CPU part only (get_all()
+    calls .cuda(); rays_o / rays_d / rgb are read from the object)."""
+    from gpnerf.sample_ray import RaySamplerSingleImage  # reference
+    arrays = {}
+    c = cases.g6_sample_ray()
+    for tag, cc in c.items():
+        s = RaySamplerSingleImage(cases.g6_data(cc), "cpu", render_stride=int(cc["stride"]))
+        d, o = np_(s.rays_d), np_(s.rays_o)
+        if tag == "small":
+            arrays.update({"small_rays_d": d, "small_rays_o": o, "small_rgb": np_(s.rgb)})
+        else:  # 76,800 rays: every 97th ray + fp64 checksums
+            arrays.update({"replica_rays_d_sub": d[::97].copy(), "replica_rays_o_sub": o[::97].copy(),
+                           "replica_n": np.int64(d.shape[0]),
+                           "replica_d_sum": d.astype(np.float64).sum(0),
+                           "replica_d_abs_sum": np.abs(d.astype(np.float64)).sum(0)})
+    save("g6_sample_ray", sha=cases.sha(c), **arrays)
+
+
+@torch.no_grad()
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "g6":
+        return g6()
     torch.manual_seed(0)
     proj = Projector("cpu")
 
@@ -128,6 +150,7 @@ def main():
         arrays[t + "_f3d_shape"] = np.array(b["feats_out_3d"].shape)
         arrays[t + "_f3d_sum"] = np_(b["feats_out_3d"].double().reshape(c["H"], c["W"], -1, 512).sum(-1))
     save("g5_render_image", sha=cases.sha(c), **arrays)
+    g6()
 
 
 if __name__ == "__main__":

@@ -535,3 +535,45 @@ def test_render_single_image_vs_golden(dev, net, prec, golden):
         errs[t + "_f3d_sum"] = rel(f3.double().reshape(c["H"], c["W"], -1, 512).sum(-1),
                                    g[t + "_f3d_sum"])
     assert max(errs.values()) < TOL, errs
+
+
+# ------------------------------------------------------------------------------ ray generation (8(f) rank 1)
+def test_ray_sampler_bit_exact(dev, golden):
+    """RaySamplerSingleImage on the device vs the reference's own sampler (golden g6): rays_o / rays_d
+    bit-exact, get_all() / random_sample() dictionaries as in reference sample_ray.py:134-214."""
+    from gp_nerf_amd import sample_ray as sr
+    g = golden("g6_sample_ray")
+    c = cases.g6_sample_ray()
+    assert np.array_equal(cases.sha(c), g["sha"])
+    for tag, cc in c.items():
+        s = sr.RaySamplerSingleImage(cases.g6_data(cc), dev, render_stride=int(cc["stride"]))
+        d, o = s.rays_d.cpu().numpy(), s.rays_o.cpu().numpy()
+        if tag == "small":
+            assert np.array_equal(d, g["small_rays_d"]) and np.array_equal(o, g["small_rays_o"])
+            assert np.array_equal(s.rgb.numpy(), g["small_rgb"])
+        else:
+            assert d.shape[0] == int(g["replica_n"])
+            assert np.array_equal(d[::97], g["replica_rays_d_sub"])
+            assert np.array_equal(o[::97], g["replica_rays_o_sub"])
+            assert np.array_equal(d.astype(np.float64).sum(0), g["replica_d_sum"])
+            assert np.array_equal(np.abs(d.astype(np.float64)).sum(0), g["replica_d_abs_sum"])
+        allr = s.get_all()
+        assert set(allr) == {"ray_o", "ray_d", "depth_range", "camera", "true_depth", "rgb", "src_rgbs",
+                             "labels", "src_labels", "src_cameras"}
+        assert allr["ray_o"].is_cuda and allr["rgb"].is_cuda and allr["true_depth"] is None
+    # random_sample: the module RandomState (seed 234) picks the same pixels as the reference would;
+    # the gathered rays equal the full-image rays at those indices, and the index kernel path agrees
+    cc = c["small"]
+    s = sr.RaySamplerSingleImage(cases.g6_data(cc), dev, render_stride=1)
+    sr.rng.seed(234)
+    r = s.random_sample(100, "uniform")
+    want = np.random.RandomState(234).choice(s.H * s.W, size=(100,), replace=False)
+    assert np.array_equal(r["selected_inds"], want)
+    assert np.array_equal(r["ray_d"].cpu().numpy(), g["small_rays_d"][want])
+    assert np.array_equal(r["rgb"].cpu().numpy(), g["small_rgb"][want])
+    o2, d2 = s._generate(s.H, s.W, s.intrinsics, s.c2w_mat, inds=want)
+    assert np.array_equal(d2.cpu().numpy(), g["small_rays_d"][want])
+    r = s.random_sample(50, "center", center_ratio=0.5)
+    assert r["ray_o"].shape == (50, 3) and r["selected_inds"].max() < s.H * s.W
+    with pytest.raises(Exception):
+        s.random_sample(10, "nope")

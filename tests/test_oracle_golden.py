@@ -124,3 +124,23 @@ def test_g5_render_single_image_chunk_invariance(golden):
         f3 = outs[1][lvl]["feats_out_3d"]
         assert tuple(f3.shape) == tuple(g[t + "_f3d_shape"])
         _close(f3.double().reshape(c["H"], c["W"], -1, 512).sum(-1), g[t + "_f3d_sum"], atol=1e-4)
+
+
+def test_g6_sample_ray_bit_exact(golden):
+    """Ray generation (reference sample_ray.py:108-132): the restatement equals the reference's own
+    RaySamplerSingleImage bit for bit."""
+    g = golden("g6_sample_ray")
+    c = cases.g6_sample_ray()
+    _same_inputs(c, g)
+    for tag, cc in c.items():
+        cam = cc["camera"]
+        H, W = int(cam[0, 0]), int(cam[0, 1])
+        o, d = oracle.sample_ray.get_rays_single_image(H, W, cam[:, 2:18].reshape(-1, 4, 4),
+                                                       cam[:, 18:34].reshape(-1, 4, 4), int(cc["stride"]))
+        if tag == "small":
+            assert np.array_equal(d.numpy(), g["small_rays_d"]) and np.array_equal(o.numpy(), g["small_rays_o"])
+        else:
+            assert d.shape[0] == int(g["replica_n"])
+            assert np.array_equal(d.numpy()[::97], g["replica_rays_d_sub"])
+            assert np.array_equal(o.numpy()[::97], g["replica_rays_o_sub"])
+            assert np.array_equal(d.numpy().astype(np.float64).sum(0), g["replica_d_sum"])

@@ -49,19 +49,41 @@ def _strided_hw(ray_sampler, render_stride):
     return (len(range(0, ray_sampler.H, render_stride)), len(range(0, ray_sampler.W, render_stride)))
 
 
+_PINNED = {}  # (level, key) -> pinned host buffer reused across images (page-locked D2H runs at PCIe speed)
+
+
+def _to_host(t, tag):
+    """One asynchronous copy into a cached page-locked buffer (the reference's per-chunk `.cpu()` into
+    pageable memory, render_image.py:78-85, costs more than the rendering of a small image).  The
+    returned CPU tensor is a fresh clone, so results of successive images do not alias."""
+    buf = _PINNED.get(tag)
+    if buf is None or buf.numel() < t.numel() or buf.dtype != t.dtype:
+        buf = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
+        _PINNED[tag] = buf
+    view = buf[: t.numel()].view(t.shape)
+    view.copy_(t, non_blocking=True)
+    return view
+
+
 def _merge(acc, Hs, Ws):
     """concat + reshape (reference render_image.py:87-119)."""
+    staged = []
     for lvl in ("outputs_coarse", "outputs_fine"):
         if acc[lvl] is None:
             continue
         for k in list(acc[lvl]):
             if k == "random_sigma":
                 continue
-            cat = torch.cat(acc[lvl][k], dim=0).cpu()
-            if k == "feats_out":
-                acc[lvl][k] = cat.reshape((Hs, Ws, 512, -1)).squeeze()
-            else:
-                acc[lvl][k] = cat.reshape((Hs, Ws, -1)).squeeze()
+            cat = torch.cat(acc[lvl][k], dim=0)
+            staged.append((lvl, k, _to_host(cat, (lvl, k)) if cat.is_cuda else cat))
+    if staged:
+        torch.cuda.synchronize()
+    for lvl, k, host in staged:
+        cat = host.clone()
+        if k == "feats_out":
+            acc[lvl][k] = cat.reshape((Hs, Ws, 512, -1)).squeeze()
+        else:
+            acc[lvl][k] = cat.reshape((Hs, Ws, -1)).squeeze()
     return acc
 
 

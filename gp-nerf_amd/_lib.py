@@ -88,6 +88,7 @@ _SIGS = {
     "gpn_sample_pdf": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "gpn_raw2outputs": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
     "gpn_rays_single_image": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_longlong, _P, _P, _P]),
+    "gpn_argmax_labels": (C.c_int, [_P, C.c_int, C.c_longlong, _P, _P, _P]),
     "gpn_repack_nhwc": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "gpn_project_gather": (C.c_int, [C.POINTER(ProjectArgs), _P]),
     "gpn_posenc": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),

@@ -296,3 +296,35 @@ extern "C" int gpn_rays_single_image(const float* M, const float* origin, int H,
   GPN_LAUNCH_CHECK("k_rays_single_image");
   return GPN_OK;
 }
+
+// ------------------------------------------------------------------------------------ semantic labels
+// Label epilogue of the semantic branch (reference eval_gpnerf.py:201-206 + loss.py:293-300): the
+// caller permutes the head's logits [1,C,H,W] to NHWC and takes argmax over the classes on the host
+// path; here one pass over the NCHW logits writes the int64 label image directly (first maximal
+// index, as torch.argmax; a NaN counts as maximal).  Pixel-major threads: every class plane is read
+// with fully coalesced loads.
+__global__ void k_argmax_labels(const float* __restrict__ logits, int C, long long HW,
+                                long long* __restrict__ labels, unsigned char* __restrict__ labels_u8) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= HW) return;
+  float best = logits[p];
+  int arg = 0;
+  for (int c = 1; c < C; ++c) {
+    const float v = logits[(long long)c * HW + p];
+    if (v > best || (v != v && best == best)) best = v, arg = c;
+  }
+  if (labels) labels[p] = arg;
+  if (labels_u8) labels_u8[p] = (unsigned char)arg;
+}
+
+extern "C" int gpn_argmax_labels(const float* logits, int C, long long HW, long long* labels,
+                                 unsigned char* labels_u8, gpn_stream_t stream) {
+  GPN_REQUIRE(C >= 1 && C <= 256, "gpn_argmax_labels: class count must be in [1,256] (got %d)", C);
+  GPN_REQUIRE(HW >= 0, "gpn_argmax_labels: negative pixel count");
+  if (HW == 0) return GPN_OK;
+  GPN_REQUIRE(logits && (labels || labels_u8), "gpn_argmax_labels: null pointer");
+  hipLaunchKernelGGL(k_argmax_labels, dim3(gpn_ceil_div(HW, 256)), dim3(256), 0, (hipStream_t)stream,
+                     logits, C, HW, labels, labels_u8);
+  GPN_LAUNCH_CHECK("k_argmax_labels");
+  return GPN_OK;
+}

@@ -10,10 +10,37 @@ kaiming_normal_(fan_out, relu).  The training-only distillation / depth-guided l
 out of scope (loss code) and raise.  The reference hard-codes a 120x160 feature image (:95); here
 the size is taken from the input (identical for 120x160).
 """
+import ctypes as C
+
 import numpy as np
 import torch
 from torch import nn
 from torch.nn import functional as F
+
+from . import _lib
+
+
+def semantic_labels(logits, dtype=torch.int64):
+    """Label image of the head's logits [1,C,H,W] (or [C,H,W]): what the reference obtains as
+    `sems.permute(0,2,3,1).argmax(dim=-1)` (eval_gpnerf.py:201-206, loss.py:293-300), in one HIP
+    kernel over the NCHW logits.  dtype int64 (reference) or uint8 (1 byte per pixel, for gathers)."""
+    x = _lib.dev_f32(_lib.as_f32c(logits), "logits")
+    if x.dim() == 4:
+        if x.shape[0] != 1:
+            raise ValueError("semantic_labels: one image at a time (batch %d)" % x.shape[0])
+        x = x[0]
+    if x.dim() != 3:
+        raise ValueError("semantic_labels: expected [1,C,H,W] or [C,H,W]")
+    Cn, H, W = x.shape
+    if dtype not in (torch.int64, torch.uint8):
+        raise ValueError("semantic_labels: dtype must be torch.int64 or torch.uint8")
+    out = torch.empty((H, W), dtype=dtype, device=x.device)
+    p64 = _lib.ptr(out) if dtype == torch.int64 else None
+    p8 = _lib.ptr(out) if dtype == torch.uint8 else None
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().gpn_argmax_labels(_lib.ptr(x), Cn, H * W, p64, p8, _lib.stream()),
+                   "gpn_argmax_labels")
+    return out
 
 
 class _ConvGNReLU(nn.Conv2d):
@@ -63,3 +90,8 @@ class NeRFSemSegFPNHead(nn.Module):
                 x = x + self.scale_heads[i](chunk)
         out = self.predictor(x)
         return F.interpolate(out, scale_factor=2, mode="bilinear", align_corners=True)
+
+    @torch.no_grad()
+    def labels(self, deep_feats, dtype=torch.int64):
+        """Eval-branch logits followed by the label epilogue (`semantic_labels`): [2h, 2w] labels."""
+        return semantic_labels(self.forward(deep_feats), dtype)

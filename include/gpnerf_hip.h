@@ -80,6 +80,14 @@ int gpn_rays_single_image(const float* M, const float* origin, int H, int W, int
                           const long long* inds, long long n_inds, float* rays_o, float* rays_d,
                           gpn_stream_t stream);
 
+/* Label epilogue of the semantic branch, reference eval_gpnerf.py:201-206 (permute to NHWC) +
+ * loss.py:293-300 (argmax over classes).  logits [C,HW] (the head's NCHW output of one image) ->
+ * labels [HW] int64 and/or labels_u8 [HW] (either may be NULL): first maximal index, NaN counts as
+ * maximal (torch.argmax).  C <= 256.  The 1-byte form is what a multi-GPU caller gathers when only
+ * labels are needed (1 B/pixel instead of 2 KB/ray of features). */
+int gpn_argmax_labels(const float* logits, int C, long long HW, long long* labels,
+                      unsigned char* labels_u8, gpn_stream_t stream);
+
 /* ------------------------------------------------------------------ projector (subsystem 1) */
 
 /* NCHW -> NHWC repack of a source-view map stack (done once per image; the reference samples NCHW

@@ -537,6 +537,41 @@ def test_render_single_image_vs_golden(dev, net, prec, golden):
     assert max(errs.values()) < TOL, errs
 
 
+def test_render_rays_stress_shape(dev, net, prec):
+    """BASELINE.json configs[4] shape on a small image: 16 source views (visibility patterns hashed into
+    the counting-sort bins, V > 12), 96 coarse + 32 importance samples (128-sample ray attention),
+    ragged ray count; HIP path vs the CPU oracle.  Fine level: rays whose importance samples differ
+    between the two platforms (inverse-CDF knife edges) are left out."""
+    from gp_nerf_amd import synth
+    from gp_nerf_amd.projection import Projector
+    from gp_nerf_amd.render_ray import render_rays
+    K = synth.scaled_intrinsics(synth.SCANNET_K, 0.3, 0.3)
+    sc = synth.Scene(72, 96, 16, K, (0.1, 6.0), seed=99, rig=dict(dx=0.06, dy=0.02, yaw_deg=-1.5))
+    sel = (torch.arange(37) * 173) % sc.rays_o.shape[0]
+    rb = sc.ray_batch()
+    rb["ray_o"], rb["ray_d"] = sc.rays_o[sel].contiguous(), sc.rays_d[sel].contiguous()
+    want = oracle.render.render_rays(rb, cases.weights(), sc.featmaps, sc.deep_semantics, N_samples=96,
+                                     inv_uniform=True, N_importance=32, det=True, ret_alpha=True)
+    got = render_rays(to(dev, rb), _model(net), sc.featmaps.to(dev), sc.deep_semantics.to(dev),
+                      Projector(dev), N_samples=96, inv_uniform=True, N_importance=32, det=True,
+                      ret_alpha=True, single_net=True)
+    _, zc = oracle.sampling.sample_along_camera_ray(rb["ray_o"], rb["ray_d"], rb["depth_range"], 96,
+                                                    inv_uniform=True, det=True)
+    zf = [oracle.sampling.sample_fine_pts(True, 32, True, 96, rb, w.clone(), zc)[1]
+          for w in (got["outputs_coarse"]["weights"].cpu(), want["outputs_coarse"]["weights"])]
+    same = (zf[0] - zf[1]).abs().amax(-1) <= 1e-5 * zf[1].abs().amax(-1)
+    assert same.float().mean() > 0.8, "too few comparable rays"
+    errs = {}
+    for lvl in ("outputs_coarse", "outputs_fine"):
+        assert got[lvl]["weights"].shape[1] == (96 if lvl == "outputs_coarse" else 128)
+        for k in ("rgb", "depth", "weights", "feats_out", "feats_out_3d"):
+            a, b = got[lvl][k].cpu(), want[lvl][k]
+            if lvl == "outputs_fine":
+                a, b = a[same], b[same]
+            errs[lvl + "/" + k] = rel(a, b)
+    assert max(errs.values()) < TOL, errs
+
+
 # ------------------------------------------------------------------------------ ray generation (8(f) rank 1)
 def test_ray_sampler_bit_exact(dev, golden):
     """RaySamplerSingleImage on the device vs the reference's own sampler (golden g6): rays_o / rays_d
@@ -577,3 +612,30 @@ def test_ray_sampler_bit_exact(dev, golden):
     assert r["ray_o"].shape == (50, 3) and r["selected_inds"].max() < s.H * s.W
     with pytest.raises(Exception):
         s.random_sample(10, "nope")
+
+
+# ------------------------------------------------------------------------------ semantic labels (8(f) rank 3)
+def test_semantic_labels_bit_exact(dev):
+    """Label epilogue vs torch's CPU argmax over the NHWC-permuted logits (reference eval_gpnerf.py:
+    201-206, loss.py:296): ties resolve to the first class, NaN counts as maximal, both label dtypes."""
+    from gp_nerf_amd.semantic_branch import NeRFSemSegFPNHead, semantic_labels
+    g = torch.Generator().manual_seed(5)
+    for Cn, H, W in ((21, 48, 64), (52, 30, 41), (1, 3, 5)):
+        lg = torch.randn((1, Cn, H, W), generator=g)
+        lg[0, :, 0, 0] = 0.25                      # full tie -> class 0
+        if Cn > 4:
+            lg[0, 3, 1, 1] = lg[0, 1, 1, 1] = 9.0  # tie of two classes -> the lower index
+            lg[0, 2, 2, 2] = float("nan")
+        want = lg.permute(0, 2, 3, 1).argmax(dim=-1)[0]
+        got = semantic_labels(lg.to(dev))
+        assert got.dtype == torch.int64 and torch.equal(got.cpu(), want)
+        got8 = semantic_labels(lg[0].to(dev), torch.uint8)
+        assert got8.dtype == torch.uint8 and torch.equal(got8.cpu().long(), want)
+    # through the head: labels(feats) == argmax of its own logits
+    args = types.SimpleNamespace()
+    head = NeRFSemSegFPNHead(args, num_classes=20).to(dev).eval()
+    feats = torch.randn((1, 512, 24, 32), generator=g).to(dev)
+    logits = head(feats)
+    assert torch.equal(head.labels(feats).cpu(), logits.cpu().permute(0, 2, 3, 1).argmax(dim=-1)[0])
+    with pytest.raises(RuntimeError):
+        semantic_labels(torch.zeros(1, 3, 4, 4))  # CPU tensor: no fallback

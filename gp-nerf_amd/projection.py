@@ -70,6 +70,13 @@ class Projector:
         """[V,C,H,W] device tensor -> cached NHWC copy."""
         k = _key(maps)
         hit = self._map_cache.get(k)
+        if hit is None and maps.dtype == torch.float32 and maps.is_cuda and maps.dim() == 4 and \
+                maps.permute(0, 2, 3, 1).is_contiguous():
+            # channels_last map (the encoders of feature_network.py emit this): already NHWC in memory
+            hit = (maps.permute(0, 2, 3, 1), maps)
+            if len(self._map_cache) > 8:
+                self._map_cache.clear()
+            self._map_cache[k] = hit
         if hit is None:
             src = _lib.dev_f32(_lib.as_f32c(maps), "feature maps")
             V, Cc, H, W = src.shape

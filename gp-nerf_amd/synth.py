@@ -244,3 +244,20 @@ def sem_head_state_dict(seed=9012, num_classes=20):
             val = hash_normal(seed, 200 + t, shape) * np.float32(math.sqrt(2.0 / fan_out))
         sd[name] = torch.from_numpy(val.astype(np.float32))
     return sd
+
+
+def hashed_state_dict(shapes, seed):
+    """Deterministic weights for a conv net given [(name, shape)] in state-dict order: conv / linear
+    weights U(+-1/sqrt(fan_in)), norm weights 1 + 0.1 n, every bias 0.1 n (n = hashed unit normal)."""
+    sd = {}
+    for t, (name, shape) in enumerate(shapes):
+        shape = tuple(shape)
+        if name.endswith("weight") and len(shape) >= 2:
+            bound = 1.0 / math.sqrt(float(np.prod(shape[1:])))
+            val = (hash_uniform(seed, 500 + t, shape).astype(np.float64) * 2.0 - 1.0) * bound
+        elif name.endswith("weight"):
+            val = 1.0 + 0.1 * hash_normal(seed, 500 + t, shape).astype(np.float64)
+        else:
+            val = 0.1 * hash_normal(seed, 500 + t, shape).astype(np.float64)
+        sd[name] = torch.from_numpy(val.astype(np.float32))
+    return sd

@@ -12,4 +12,4 @@ container; the generating script and the vectors live in `tests/golden/`.  The o
 semantic head (`sem_head.py`): the reference module needs detectron2/fvcore, which are absent, and
 the reference ships no test or fixture for it -> that function is "parity unpinned".
 """
-from . import gnt, projector, render, sample_ray, sampling, sem_head  # noqa: F401
+from . import encoders, gnt, projector, render, sample_ray, sampling, sem_head  # noqa: F401

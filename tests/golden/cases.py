@@ -120,3 +120,43 @@ def g6_data(c):
     """The `data` dict RaySamplerSingleImage reads (keys of reference sample_ray.py:41-48)."""
     return {"rgb": c["rgb"], "camera": c["camera"], "rgb_path": "synthetic", "true_depth": None,
             "depth_mask": None, "depth_range": c["depth_range"]}
+
+
+def _resunet_shapes():
+    """ResUNet state-dict layout (reference feature_network.py:164-291, resnet34 / single_net / 32 ch)."""
+    out = [("conv1.weight", (64, 3, 7, 7)), ("bn1.weight", (64,)), ("bn1.bias", (64,))]
+    cin = 64
+    for li, (cout, n) in enumerate(((64, 3), (128, 4), (256, 6)), start=1):
+        for b in range(n):
+            p = "layer%d.%d." % (li, b)
+            out += [(p + "conv1.weight", (cout, cin if b == 0 else cout, 3, 3)), (p + "bn1.weight", (cout,)),
+                    (p + "bn1.bias", (cout,)), (p + "conv2.weight", (cout, cout, 3, 3)),
+                    (p + "bn2.weight", (cout,)), (p + "bn2.bias", (cout,))]
+            if b == 0:
+                out += [(p + "downsample.0.weight", (cout, cin, 1, 1)), (p + "downsample.1.weight", (cout,)),
+                        (p + "downsample.1.bias", (cout,))]
+        cin = cout
+    for name, ci, co in (("upconv3.conv", 256, 128), ("iconv3", 256, 128), ("upconv2.conv", 128, 64),
+                         ("iconv2", 128, 32)):
+        out += [(name + ".conv.weight", (co, ci, 3, 3)), (name + ".conv.bias", (co,)),
+                (name + ".bn.weight", (co,)), (name + ".bn.bias", (co,))]
+    out += [("out_conv.weight", (32, 32, 1, 1)), ("out_conv.bias", (32,))]
+    return out
+
+
+def fpn_shapes(in_channels=(64, 64, 128, 256), out_channels=128):
+    out = []
+    for i, c in enumerate(in_channels):
+        out += [("lateral_convs.%d.conv.weight" % i, (out_channels, c, 1, 1)),
+                ("lateral_convs.%d.conv.bias" % i, (out_channels,))]
+    for i, c in enumerate(in_channels):
+        out += [("fpn_convs.%d.conv.weight" % i, (out_channels, out_channels, 3, 3)),
+                ("fpn_convs.%d.conv.bias" % i, (out_channels,))]
+    return out
+
+
+def g7_encoders():
+    """3 source images of 52x72 (odd H/16, W/16 sizes exercise skipconnect's padding) + hashed weights."""
+    x = torch.from_numpy(synth.hash_uniform(4242, 9, (3, 3, 52, 72)))
+    return dict(x=x, resunet=synth.hashed_state_dict(_resunet_shapes(), 777),
+                fpn=synth.hashed_state_dict(fpn_shapes(), 778))

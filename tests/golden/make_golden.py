@@ -72,9 +72,30 @@ def g6():
 
 
 @torch.no_grad()
+def g7():
+    """G7: the reference's own ResUNet (feature_network.py:164-313), eval mode, CPU.  (Its FPN needs
+    mmcv / mmdet -- absent -- so the FPN restatement stays unpinned.)"""
+    from gpnerf.feature_network import ResUNet  # reference
+    c = cases.g7_encoders()
+    net = ResUNet(coarse_out_ch=32, fine_out_ch=32, single_net=True)
+    net.load_state_dict(c["resunet"], strict=True)
+    net.eval()
+    coarse, fine, feats = net(c["x"])
+    assert fine is coarse
+    arrays = {"coarse": np_(coarse)}
+    for i, f in enumerate(feats):
+        arrays["x%d_shape" % i] = np.array(f.shape)
+        arrays["x%d_head" % i] = np_(f[:, :4])
+        arrays["x%d_sum" % i] = np_(f.double().sum(1))
+    save("g7_resunet", sha=cases.sha(dict(x=c["x"], resunet=c["resunet"])), **arrays)
+
+
+@torch.no_grad()
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "g6":
         return g6()
+    if len(sys.argv) > 1 and sys.argv[1] == "g7":
+        return g7()
     torch.manual_seed(0)
     proj = Projector("cpu")
 
@@ -151,6 +172,7 @@ def main():
         arrays[t + "_f3d_sum"] = np_(b["feats_out_3d"].double().reshape(c["H"], c["W"], -1, 512).sum(-1))
     save("g5_render_image", sha=cases.sha(c), **arrays)
     g6()
+    g7()
 
 
 if __name__ == "__main__":

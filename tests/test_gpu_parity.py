@@ -639,3 +639,47 @@ def test_semantic_labels_bit_exact(dev):
     assert torch.equal(head.labels(feats).cpu(), logits.cpu().permute(0, 2, 3, 1).argmax(dim=-1)[0])
     with pytest.raises(RuntimeError):
         semantic_labels(torch.zeros(1, 3, 4, 4))  # CPU tensor: no fallback
+
+
+# ------------------------------------------------------------------------------ encoders (8(f) rank 2)
+def test_encoders_vs_golden_and_nhwc_handoff(dev, golden):
+    """ResUNet / FPN modules on the device: vs the reference's own ResUNet (golden g7), vs the CPU
+    restatement (FPN: parity unpinned, mmcv absent), and the zero-copy channels_last hand-off of their
+    maps into the projector (same bits as the repacked NCHW path)."""
+    from gp_nerf_amd.feature_network import FPN, ResUNet
+    from gp_nerf_amd.projection import Projector
+    g = golden("g7_resunet")
+    c = cases.g7_encoders()
+    net = ResUNet(coarse_out_ch=32, fine_out_ch=32, single_net=True)
+    net.load_state_dict(c["resunet"], strict=True)
+    fpn = FPN(in_channels=[64, 64, 128, 256], out_channels=128, concat_out=True)
+    fpn.load_state_dict(c["fpn"], strict=True)
+    net, fpn = net.to(dev).eval(), fpn.to(dev).eval()
+    coarse, fine, feats = net(c["x"].to(dev))
+    assert fine is coarse and coarse.permute(0, 2, 3, 1).is_contiguous()
+    errs = {"coarse": rel(coarse, g["coarse"])}
+    for i, f in enumerate(feats):
+        assert tuple(f.shape) == tuple(g["x%d_shape" % i])
+        errs["x%d" % i] = rel(f[:, :4], g["x%d_head" % i])
+        errs["x%d_sum" % i] = rel(f.double().sum(1), g["x%d_sum" % i])
+    deep = fpn(feats)
+    _, _, ofeats = oracle.encoders.resunet_forward(c["resunet"], c["x"])
+    errs["fpn"] = rel(deep, oracle.encoders.fpn_forward(c["fpn"], ofeats))
+    assert max(errs.values()) < TOL, errs
+    assert tuple(deep.shape) == (3, 512, 26, 36) and deep.permute(0, 2, 3, 1).is_contiguous()
+    with pytest.raises(RuntimeError):
+        net(c["x"])  # CPU input: no fallback
+    # hand-off: channels_last maps are taken as they are (no repack) and give the same gathers
+    from gp_nerf_amd import synth
+    H, W, V = 52, 72, 3
+    K = synth.scaled_intrinsics(synth.SCANNET_K, W / 320.0, H / 240.0)
+    sc = synth.Scene(H, W, V, K, (0.1, 6.0), seed=5, rig=dict(dx=0.05, dy=0.01, yaw_deg=-1.0))
+    rb = to(dev, sc.ray_batch(start=100, count=40))
+    pts = (rb["ray_o"][:, None] + rb["ray_d"][:, None] * torch.linspace(0.5, 3.0, 8, device=dev)[None, :, None])
+    proj = Projector(dev)
+    args_ = (pts.contiguous(), rb["camera"], rb["src_rgbs"], rb["src_cameras"])
+    a = proj.compute(*args_, coarse, deep)
+    assert proj._nhwc(deep).data_ptr() == deep.data_ptr()
+    b = proj.compute(*args_, coarse.contiguous(), deep.contiguous())  # NCHW copies -> repack kernel
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)

@@ -144,3 +144,19 @@ def test_g6_sample_ray_bit_exact(golden):
             assert np.array_equal(d.numpy()[::97], g["replica_rays_d_sub"])
             assert np.array_equal(o.numpy()[::97], g["replica_rays_o_sub"])
             assert np.array_equal(d.numpy().astype(np.float64).sum(0), g["replica_d_sum"])
+
+
+def test_g7_resunet(golden):
+    """2-D encoder restatement vs the reference's own ResUNet (same CPU conv library: 1e-5)."""
+    g = golden("g7_resunet")
+    c = cases.g7_encoders()
+    assert np.array_equal(cases.sha(dict(x=c["x"], resunet=c["resunet"])), g["sha"])
+    coarse, fine, feats = oracle.encoders.resunet_forward(c["resunet"], c["x"])
+    _close(coarse, g["coarse"], rtol=1e-4, atol=1e-5)
+    for i, f in enumerate(feats):
+        assert tuple(f.shape) == tuple(g["x%d_shape" % i])
+        _close(f[:, :4], g["x%d_head" % i], rtol=1e-4, atol=1e-5)
+        _close(f.double().sum(1), g["x%d_sum" % i], rtol=1e-4, atol=1e-5)
+    # FPN: parity unpinned (mmcv / mmdet absent); shape + determinism only
+    out = oracle.encoders.fpn_forward(c["fpn"], feats)
+    assert tuple(out.shape) == (3, 512, 26, 36) and torch.isfinite(out).all()

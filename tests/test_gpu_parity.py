@@ -683,3 +683,75 @@ def test_encoders_vs_golden_and_nhwc_handoff(dev, golden):
     b = proj.compute(*args_, coarse.contiguous(), deep.contiguous())  # NCHW copies -> repack kernel
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+# ------------------------------------------------------------------------------ model container + view driver (8(f) rank 4)
+def test_checkpoint_roundtrip_and_render_view(dev, tmp_path):
+    """GPNeRFModel reads a checkpoint in the reference's format (model.py:133-173) and `render_view`
+    (the compute part of log_view, eval_gpnerf.py:172-206) runs sampler -> encoders -> render ->
+    semantic head -> labels on the device; the whole chain is compared with the CPU oracle chain."""
+    from gp_nerf_amd import synth
+    from gp_nerf_amd.eval_view import render_view
+    from gp_nerf_amd.model import GPNeRFModel
+    from gp_nerf_amd.projection import Projector
+    from gp_nerf_amd.sample_ray import RaySamplerSingleImage
+    H, W, V = 48, 64, 4
+    ck = tmp_path / "model_000123.pth"
+    enc = cases.g7_encoders()
+    head_sd = synth.hashed_state_dict(synth.sem_head_param_shapes(), 901)
+    gnt_sd = cases.weights()
+    torch.save({"optimizer": {"state": {}, "param_groups": []}, "scheduler": {"last_epoch": 7},
+                "net_coarse": gnt_sd, "feature_net": enc["resunet"], "feature_fpn": enc["fpn"],
+                "sem_seg_head": head_sd}, ck)
+    args = types.SimpleNamespace(netwidth=64, trans_depth=8, save_feature=False, semantic_model="fpn",
+                                 num_classes=20, coarse_feat_dim=32, fine_feat_dim=32, single_net=True,
+                                 N_importance=8, N_samples=16, inv_uniform=True, white_bkgd=False,
+                                 chunk_size=1000, render_stride=1, local_rank=0, ckpt_path=str(ck),
+                                 no_reload=False, rootdir=str(tmp_path), expname="none", n_p=0)
+    model = GPNeRFModel(args)
+    assert model.start_step == 123
+    for k, v in gnt_sd.items():
+        assert torch.equal(model.net_coarse.state_dict()[k].cpu(), v), k
+    assert torch.equal(model.feature_fpn.state_dict()["fpn_convs.2.conv.weight"].cpu(), enc["fpn"]["fpn_convs.2.conv.weight"])
+    out = tmp_path / "resaved.pth"
+    model.save_model(str(out))
+    again = torch.load(out, weights_only=True)
+    assert set(again) == {"optimizer", "scheduler", "net_coarse", "feature_net", "feature_fpn", "sem_seg_head"}
+    assert torch.equal(again["sem_seg_head"]["predictor.bias"].cpu(), head_sd["predictor.bias"])
+
+    K = synth.scaled_intrinsics(synth.SCANNET_K, W / 320.0, H / 240.0)
+    sc = synth.Scene(H, W, V, K, (0.1, 6.0), seed=77, rig=dict(dx=0.05, dy=0.01, yaw_deg=-1.0))
+    data = {"rgb": sc.src_rgbs[0, :1].clone(), "camera": sc.camera, "rgb_path": "synthetic", "true_depth": None,
+            "depth_mask": None, "depth_range": sc.depth_range, "src_rgbs": sc.src_rgbs, "src_cameras": sc.src_cameras}
+    sampler = RaySamplerSingleImage(data, dev, render_stride=1)
+    ret, rb = render_view(args, model, sampler, Projector(dev), render_stride=1, ret_alpha=True, single_net=True,
+                          feats_out_3d=False)
+    # CPU oracle chain on the same inputs
+    src = sc.src_rgbs[0].permute(0, 3, 1, 2)
+    coarse, _, feats = oracle.encoders.resunet_forward(enc["resunet"], src)
+    deep = oracle.encoders.fpn_forward(enc["fpn"], feats)
+    o_, d_ = oracle.sample_ray.get_rays_single_image(H, W, sc.camera[:, 2:18].reshape(-1, 4, 4),
+                                                     sc.camera[:, 18:34].reshape(-1, 4, 4), 1)
+    rbc = sc.ray_batch()
+    rbc["ray_o"], rbc["ray_d"] = o_, d_
+    want = oracle.render.render_rays(rbc, gnt_sd, coarse, deep, N_samples=16, inv_uniform=True, N_importance=8,
+                                     det=True, ret_alpha=True)
+    errs = {}
+    for lvl in ("outputs_coarse", "outputs_fine"):
+        assert tuple(ret[lvl]["rgb"].shape) == (H, W, 3) and not ret[lvl]["rgb"].is_cuda
+        errs[lvl + "/rgb"] = rel(ret[lvl]["rgb"].reshape(-1, 3), want[lvl]["rgb"])
+        errs[lvl + "/depth"] = rel(ret[lvl]["depth"].reshape(-1), want[lvl]["depth"])
+    # the encoders' library convolutions differ between CPU and GPU by ~1e-5; the coarse level is
+    # continuous in the maps (fine samples sit behind an inverse-CDF lookup: a looser bound)
+    assert errs["outputs_coarse/rgb"] < 5e-4 and errs["outputs_coarse/depth"] < 5e-4, errs
+    assert errs["outputs_fine/rgb"] < 5e-2, errs
+    fo = want["outputs_coarse"]["feats_out"].reshape(H, W, 512)[::2, ::2].permute(2, 0, 1).unsqueeze(0)
+    lg = oracle.sem_head.forward(head_sd, fo)
+    sems = ret["outputs_coarse"]["sems"]
+    assert tuple(sems.shape) == (1, H, W, 21) and tuple(ret["outputs_coarse"]["labels"].shape) == (H, W)
+    assert rel(sems.permute(0, 3, 1, 2), lg) < 2e-3
+    # labels: exactly the argmax of the device logits; equal to the oracle's wherever its top-2 margin is clear
+    assert torch.equal(ret["outputs_coarse"]["labels"].cpu(), sems.cpu().argmax(dim=-1)[0])
+    top2 = lg[0].topk(2, dim=0).values
+    clear = (top2[0] - top2[1]) > 1e-2 * lg.abs().max()
+    assert torch.equal(ret["outputs_coarse"]["labels"].cpu()[clear], lg[0].argmax(dim=0)[clear])

@@ -237,9 +237,10 @@ def main():
     pts_per_launch = CHUNK * (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) / 2.0
     vstat = visibility_stats(scene, rb, ret, projector)
     live = vstat["computed_pair_fraction"]
-    # per computed (point, view) pair: feature row 256 B + ray_diff 16 B; per visible pair: logits
-    # row 256 B; per point: q in 256 + q out 256 + softmax stats 256 + order/visibility words 8
-    alg_bytes = (VIEWS * live * (256 + 16) + VIEWS * vstat["visible_pair_fraction"] * 256 +
+    # per computed (point, view) pair: feature row 256 B + ray_diff 16 B; per visible pair: the 8
+    # hidden values of attn_fc 32 B; per point: q in 256 + q out 256 + softmax stats 256 + order /
+    # visibility words 8
+    alg_bytes = (VIEWS * live * (256 + 16) + VIEWS * vstat["visible_pair_fraction"] * 32 +
                  256 + 256 + 256 + 8) * pts_per_launch
     achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
     traffic = pmc_traffic("k_view_attn")

@@ -68,13 +68,14 @@ class ProjectArgs(C.Structure):
 
 class SemArgs(C.Structure):
     _fields_ = [("R", C.c_int), ("S", C.c_int), ("V", C.c_int), ("depth", C.c_int),
-                ("logits", C.c_void_p), ("stats", C.c_void_p), ("abar", C.c_void_p),
+                ("hidden", C.c_void_p), ("stats", C.c_void_p), ("abar", C.c_void_p),
                 ("mask", C.c_void_p),
                 ("deep_dense", C.c_void_p),
                 ("deep_map", C.c_void_p), ("deep_h", C.c_int), ("deep_w", C.c_int),
                 ("xyz", C.c_void_p), ("proj", C.c_void_p),
                 ("img_h", C.c_float), ("img_w", C.c_float),
-                ("sem3d", C.c_void_p), ("pre", C.c_void_p)]
+                ("sem3d", C.c_void_p), ("pre", C.c_void_p),
+                ("attn2_w", C.c_void_p * MAX_DEPTH), ("attn2_b", C.c_void_p * MAX_DEPTH)]
 
 
 _P = C.c_void_p

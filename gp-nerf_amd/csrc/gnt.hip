@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(VA_TPB)
 k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __restrict__ feat,
             const float* __restrict__ ray_diff, const float* __restrict__ mask,
             const int* __restrict__ perm, long long N, int V, float* __restrict__ q_out,
-            float* __restrict__ logits, int logits_ld, float* __restrict__ stats, int stats_ld) {
+            float* __restrict__ hidden, int hidden_ld, float* __restrict__ stats, int stats_ld) {
   const ViewLds L = view_lds<SPL>(smem);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (tile loop, LDS-DMA base)
@@ -604,10 +604,10 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
         const int v = __builtin_ctz(live);
         live &= live - 1;
         // This pair's slot was filled by a DMA issued two iterations ago.  Younger vector-memory
-        // operations of this wave in the HOMOG form: the logits stores of the two iterations since
-        // (4 each, always issued: every lane is visible and lane 0 of a tile is a valid point) and
-        // the 5 DMA pieces of the next pair; the other forms do not count, they wait for everything.
-        if (MODE == VM_HOMOG && logits != nullptr) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VA_DMA_OPS + 8) : "memory");
+        // operations of this wave in the HOMOG form: the hidden-layer stores of the two iterations
+        // since (1 each, always issued: every lane is visible and lane 0 of a tile is a valid point)
+        // and the 5 DMA pieces of the next pair; the other forms do not count, they wait for everything.
+        if (MODE == VM_HOMOG && hidden != nullptr) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VA_DMA_OPS + 2) : "memory");
         else if (MODE == VM_HOMOG) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VA_DMA_OPS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         f4 fcur[4];
@@ -628,6 +628,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
         }
         // pos hidden layer: 4 -> 8 (ReLU), one fp32 MFMA
         f4 ph = f4_relu(mfma16(p0w, rd, ld4(L.bP0 + 4 * g)));
+        f4 ah;  // post-ReLU hidden layer of attn_fc: rows 4g..4g+3 of the (zero-padded) 16
         if constexpr (FOLD) {
           // v + pos = (Wv Wk) f + P2 h + b ; attn hidden = (A0 Wk) f + (A0 P2) h + aq : every product
           // reads the split of f and h made once here
@@ -637,7 +638,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
           xs[2] = split8(ph, f4_zero());
           lin_Sx<4, 4>(L.Wv, xs, vp, lane);
           lin_Sx<1, 4>(L.P2, xs + 2, vp, lane);
-          f4 ah = aq;
+          ah = aq;
           lin_Sx<6, 1>(L.AF, xs, &ah, lane);
           ah = f4_relu(ah);
           lin<SPL, 1, 4>(L.A2, VA_LD8, &ah, a, lane);
@@ -664,17 +665,16 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
           lin<SPL, 4, 4>(L.Wv, LDW, k, vp, lane);     // v = v_fc(k)   (reference quirk, :77)
 #pragma unroll
           for (int M = 0; M < 4; ++M) vp[M] = vp[M] + pos[M];
-          f4 ah = ld4(L.bA0 + 4 * g);
+          ah = ld4(L.bA0 + 4 * g);
           lin<SPL, 4, 1>(L.A0, LDW, ain, &ah, lane);
           ah = f4_relu(ah);
           lin<SPL, 1, 4>(L.A2, VA_LD8, &ah, a, lane);
         }
 const bool vis_v = MODE == VM_HOMOG || ((vis >> v) & 1u) != 0;
-        if (logits != nullptr && lane_ok && vis_v) {  // masked pairs are never read back
-          float* lo = logits + ((size_t)n * V + v) * logits_ld + 4 * g;
-#pragma unroll
-          for (int M = 0; M < 4; ++M) st4(lo + 16 * M, a[M]);
-        }
+        // side output for the semantic pass: the 8 hidden values (lanes g < 2), from which
+        // gpn_sem_aggregate rebuilds the 64 logits; masked pairs are never read back
+        if (hidden != nullptr && lane_ok && vis_v && g < 2)
+          st4(hidden + ((size_t)n * V + v) * hidden_ld + 4 * g, ah);
         if constexpr (MODE != VM_HOMOG) {
           if (!vis_v) {
 #pragma unroll
@@ -1235,10 +1235,23 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
 // into W3d / W2d and applied to the sampled (or dense) deep-semantic row.  Masked views have weight
 // exactly 0 and are skipped; a sample with no visible view has the uniform weight 1/V in every layer.
 #define SEM_RAYS 8
+#ifndef SEM_WAVES_PER_SIMD
+#define SEM_WAVES_PER_SIMD 2
+#endif
+typedef const __attribute__((address_space(4))) float* sem_cfp;
+__device__ __forceinline__ float rl_f(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ unsigned rl_u(unsigned v, int l) {
+  return (unsigned)__builtin_amdgcn_readlane((int)v, l);
+}
+
 template <int DEPTH>
-__global__ void __launch_bounds__(SEM_RAYS * 64, 4)  // 4 waves per SIMD: two workgroups per CU
+__global__ void __launch_bounds__(SEM_RAYS * 64, SEM_WAVES_PER_SIMD)
 k_sem(gpn_sem_args_t a) {
+  constexpr int LP = (DEPTH + 1) / 2;  // layers are processed in pairs (v_pk_fma_f32)
   __shared__ float sP[GPN_MAX_VIEWS * 12];
+  __shared__ __attribute__((aligned(16))) float sH[SEM_RAYS][LP * 16];
   const int tid = threadIdx.x, lane = tid & 63;
   // the wave index (hence the ray and every per-sample address) is wave-uniform: keep it in SGPRs
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1253,6 +1266,7 @@ k_sem(gpn_sem_args_t a) {
   if (a.deep_map != nullptr) {
     for (int i = tid; i < V * 12; i += SEM_RAYS * 64) sP[i] = a.proj[(i / 12) * 16 + (i % 12)];
   }
+  for (int i = tid; i < SEM_RAYS * LP * 16; i += SEM_RAYS * 64) (&sH[0][0])[i] = 0.0f;
   __syncthreads();
   // (Banding the workgroups of an XCD into 2-D pixel patches was measured: no gain over 1-D runs.)
   const int r = blk * SEM_RAYS + wave;
@@ -1261,51 +1275,122 @@ k_sem(gpn_sem_args_t a) {
   const int c8 = lane * 8, head = lane >> 4;  // lane == channel group
   f4 acc2a = f4_zero(), acc2b = f4_zero();
   const size_t rs = (size_t)a.deep_w * GPN_SEM;
+  const unsigned urs = (unsigned)rs;  // one map is < 2^31 floats: 32-bit element offsets inside a view
   const float inv_v = 1.0f / (float)V;
   const unsigned all_views = V >= 32 ? 0xffffffffu : ((1u << V) - 1u);
   const bool dense = a.deep_dense != nullptr;
+  // attn_fc[2] of every layer: this lane's row (its channel group) of the [64,8] weight and its
+  // bias, scaled by log2(e) so that the softmax weight is a bare v_exp_f32; layers l = 2p, 2p+1
+  // sit in the two halves of an f2 (one v_pk_fma_f32 per hidden value and layer pair)
+  f2 a2w[LP][8], a2b[LP];
+#pragma unroll
+  for (int l = 0; l < 2 * LP; ++l) {
+    f4 w0 = f4_zero(), w1 = f4_zero();
+    float b = 0.0f;
+    if (l < DEPTH) {
+      w0 = ld4(a.attn2_w[l] + lane * 8), w1 = ld4(a.attn2_w[l] + lane * 8 + 4);
+      b = a.attn2_b[l] ? a.attn2_b[l][lane] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a2w[l >> 1][k][l & 1] = w0[k] * LOG2E_F, a2w[l >> 1][4 + k][l & 1] = w1[k] * LOG2E_F;
+    a2b[l >> 1][l & 1] = b;
+  }
+  // hidden value i = 8 l + k of a pair is parked at LDS slot ((l>>1)*8 + k)*2 + (l&1): the two
+  // layers of a pair side by side, read back 4 floats (2 hidden values x 2 layers) at a time
+  const int hslot = lane < DEPTH * 8 ? ((lane >> 4) * 8 + (lane & 7)) * 2 + ((lane >> 3) & 1) : 0;
+  // Bilinear taps of a sample in every source view, one view per lane (the arithmetic of the
+  // projector, proj_common.h): element offsets inside the view's map (clamped to valid texels) and
+  // the four weights, zero for taps outside the map (grid_sample's zero padding).
+  struct TapTab {
+    unsigned o00, o01, o10, o11;
+    float wnw, wne, wsw, wse;
+  };
+  auto tap_table = [&](size_t n_) {
+    TapTab t_ = {0, 0, 0, 0, 0.f, 0.f, 0.f, 0.f};
+    if (!dense && lane < V) {
+      const float px = a.xyz[n_ * 3 + 0], py = a.xyz[n_ * 3 + 1], pz = a.xyz[n_ * 3 + 2];
+      const GpnPix pp = gpn_project(sP + lane * 12, px, py, pz);
+      const GpnTaps t = gpn_taps(pp.px, pp.py, a.img_h, a.img_w, a.deep_h, a.deep_w);
+      const int x0 = min(max(t.x0, 0), a.deep_w - 1), x1 = min(max(t.x0 + 1, 0), a.deep_w - 1);
+      const int y0 = min(max(t.y0, 0), a.deep_h - 1), y1 = min(max(t.y0 + 1, 0), a.deep_h - 1);
+      t_.o00 = (unsigned)y0 * urs + (unsigned)x0 * GPN_SEM, t_.o01 = (unsigned)y0 * urs + (unsigned)x1 * GPN_SEM;
+      t_.o10 = (unsigned)y1 * urs + (unsigned)x0 * GPN_SEM, t_.o11 = (unsigned)y1 * urs + (unsigned)x1 * GPN_SEM;
+      t_.wnw = (t.vy0 && t.vx0) ? t.nw : 0.0f, t_.wne = (t.vy0 && t.vx1) ? t.ne : 0.0f;
+      t_.wsw = (t.vy1 && t.vx0) ? t.sw : 0.0f, t_.wse = (t.vy1 && t.vx1) ? t.se : 0.0f;
+    }
+    return t_;
+  };
+  // the 8 x 16 bytes a lane needs of one (sample, view): four taps x this lane's 8 channels.
+  // Issued one pair ahead (across the sample boundary too), so a wave always has the next pair's
+  // 8 KB in flight while it rebuilds the current pair's attention weights.
+  f4 tp[8];
+  auto fetch_taps = [&](const TapTab& t_, int v_) {
+    const unsigned s00 = rl_u(t_.o00, v_), s01 = rl_u(t_.o01, v_), s10 = rl_u(t_.o10, v_), s11 = rl_u(t_.o11, v_);
+    const float* dm = a.deep_map + (size_t)v_ * a.deep_h * rs + (unsigned)c8;
+    tp[0] = ld4(dm + s00), tp[1] = ld4(dm + s00 + 4), tp[2] = ld4(dm + s01), tp[3] = ld4(dm + s01 + 4);
+    tp[4] = ld4(dm + s10), tp[5] = ld4(dm + s10 + 4), tp[6] = ld4(dm + s11), tp[7] = ld4(dm + s11 + 4);
+  };
+  auto live_of_mask = [&](float m_) {
+    const unsigned vis_ = (unsigned)__ballot(m_ != 0.0f);
+    return vis_;
+  };
   // visibility bits: lane v reads the mask of view v, one sample ahead
   float mv_next = lane < V ? a.mask[(size_t)rc * S * V + lane] : 0.0f;
+  TapTab tab_next = tap_table((size_t)rc * S);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) tp[k] = f4_zero();
+  if (!dense) {
+    const unsigned v0 = live_of_mask(mv_next);
+    fetch_taps(tab_next, __builtin_ctz(v0 != 0 ? v0 : all_views));
+  }
   for (int s = 0; s < S; ++s) {
     const size_t n = (size_t)rc * S + s;
     // per-sample state, every load issued before the first use: softmax stats and mean ray
-    // attention of every layer, the sample position, the next sample's mask
+    // attention of every layer, the next sample's mask and tap table
     const float mv = mv_next;
     if (s + 1 < S) mv_next = lane < V ? a.mask[(n + 1) * V + lane] : 0.0f;
-    float lse[DEPTH], ab[DEPTH];
+    const TapTab tab = tab_next;
+    if (s + 1 < S) tab_next = tap_table(n + 1);
+    f2 bl[LP], ab[LP];
     const float* abp = a.abar + n * (DEPTH * 4);
     const float* stp = a.stats + n * (DEPTH * C64);
 #pragma unroll
-    for (int l = 0; l < DEPTH; ++l) {
-      ab[l] = abp[4 * l + head];
-      lse[l] = __builtin_nontemporal_load(stp + (C64 * l + lane));
+    for (int l = 0; l < 2 * LP; ++l) {
+      float abv = 0.0f, lse = 0.0f;
+      if (l < DEPTH) {
+        abv = abp[4 * l + head];
+        lse = __builtin_nontemporal_load(stp + (C64 * l + lane));
+      }
+      ab[l >> 1][l & 1] = abv;
+      bl[l >> 1][l & 1] = lse;
     }
-    float px = 0.f, py = 0.f, pz = 0.f;
-    if (!dense) px = a.xyz[n * 3 + 0], py = a.xyz[n * 3 + 1], pz = a.xyz[n * 3 + 2];
-    const unsigned vis = (unsigned)__ballot(mv != 0.0f);
+    const unsigned vis = live_of_mask(mv);
+    unsigned live = vis != 0 ? vis : all_views;
+    unsigned live_n = 0;  // live views of the next sample
+    if (s + 1 < S) {
+      const unsigned vn = live_of_mask(mv_next);
+      live_n = vn != 0 ? vn : all_views;
+    }
+    // hidden layer of attn_fc for all DEPTH layers of a (sample, view): 8*DEPTH floats, one per lane,
+    // fetched one view ahead; every lane needs all of them, so they go through an LDS slot of the
+    // wave and come back as broadcast reads (same address in all lanes: conflict free)
+    float hvn = 0.f;
+    if (vis != 0 && lane < DEPTH * 8)
+      hvn = __builtin_nontemporal_load(a.hidden + (n * V + __builtin_ctz(live)) * (DEPTH * 8) + lane);
+    // bias - log-sum-exp, in log2 units: the constant part of every logit of this sample
+#pragma unroll
+    for (int p = 0; p < LP; ++p) bl[p] = (a2b[p] - bl[p]) * (f2){LOG2E_F, LOG2E_F};
     float w3u = 0.f, w2u = 0.f;  // uniform weights of an all-masked sample
 #pragma unroll
-    for (int l = 0; l < DEPTH; ++l) w3u += inv_v, w2u += ab[l] * inv_v;
+    for (int l = 0; l < DEPTH; ++l) w3u += inv_v, w2u += ab[l >> 1][l & 1] * inv_v;
     f4 acc3a = f4_zero(), acc3b = f4_zero();
-    unsigned live = vis != 0 ? vis : all_views;
-    float lgn[DEPTH];  // logits of the next live view, fetched one iteration ahead
-    if (vis != 0) {
-      const float* lgp = a.logits + (n * V + __builtin_ctz(live)) * (DEPTH * C64);
-#pragma unroll
-      for (int l = 0; l < DEPTH; ++l) lgn[l] = __builtin_nontemporal_load(lgp + (C64 * l + lane));
-    }
     while (live) {
       const int v = __builtin_ctz(live);
       live &= live - 1;
-      float lg[DEPTH];
       if (vis != 0) {
-#pragma unroll
-        for (int l = 0; l < DEPTH; ++l) lg[l] = lgn[l];
-        if (live) {
-          const float* lgp = a.logits + (n * V + __builtin_ctz(live)) * (DEPTH * C64);
-#pragma unroll
-          for (int l = 0; l < DEPTH; ++l) lgn[l] = __builtin_nontemporal_load(lgp + (C64 * l + lane));
-        }
+        if (lane < DEPTH * 8) sH[wave][hslot] = hvn;
+        if (live && lane < DEPTH * 8)
+          hvn = __builtin_nontemporal_load(a.hidden + (n * V + __builtin_ctz(live)) * (DEPTH * 8) + lane);
       }
       f4 d0, d1;
       if (dense) {
@@ -1313,45 +1398,39 @@ k_sem(gpn_sem_args_t a) {
         d0 = ld4(dd + (unsigned)c8);
         d1 = ld4(dd + (unsigned)(c8 + 4));
       } else {
-        const GpnPix pp = gpn_project(sP + v * 12, px, py, pz);
-        const GpnTaps t = gpn_taps(pp.px, pp.py, a.img_h, a.img_w, a.deep_h, a.deep_w);
-        // all four taps are loaded from clamped (always valid) addresses; out-of-map taps are
-        // zeroed afterwards, as grid_sample's zero padding does
-        const int x0 = min(max(t.x0, 0), a.deep_w - 1), x1 = min(max(t.x0 + 1, 0), a.deep_w - 1);
-        const int y0 = min(max(t.y0, 0), a.deep_h - 1), y1 = min(max(t.y0 + 1, 0), a.deep_h - 1);
-        // uniform base of the view's map + 32-bit element offsets (one map is < 2^31 floats)
-        const float* dm = a.deep_map + (size_t)v * a.deep_h * rs;
-        const unsigned urs = (unsigned)rs;
-        const float* p00 = dm + ((unsigned)y0 * urs + (unsigned)x0 * GPN_SEM + (unsigned)c8);
-        const float* p01 = dm + ((unsigned)y0 * urs + (unsigned)x1 * GPN_SEM + (unsigned)c8);
-        const float* p10 = dm + ((unsigned)y1 * urs + (unsigned)x0 * GPN_SEM + (unsigned)c8);
-        const float* p11 = dm + ((unsigned)y1 * urs + (unsigned)x1 * GPN_SEM + (unsigned)c8);
-        f4 tnw[2] = {ld4(p00), ld4(p00 + 4)}, tne[2] = {ld4(p01), ld4(p01 + 4)};
-        f4 tsw[2] = {ld4(p10), ld4(p10 + 4)}, tse[2] = {ld4(p11), ld4(p11 + 4)};
-        const float znw = (t.vy0 && t.vx0) ? 1.0f : 0.0f, zne = (t.vy0 && t.vx1) ? 1.0f : 0.0f;
-        const float zsw = (t.vy1 && t.vx0) ? 1.0f : 0.0f, zse = (t.vy1 && t.vx1) ? 1.0f : 0.0f;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          if (znw == 0.0f) tnw[h] = f4_zero();
-          if (zne == 0.0f) tne[h] = f4_zero();
-          if (zsw == 0.0f) tsw[h] = f4_zero();
-          if (zse == 0.0f) tse[h] = f4_zero();
-        }
+        // this view's tap weights: wave-uniform (scalar registers); out-of-map taps carry weight 0
+        const float tnw_w = rl_f(tab.wnw, v), tne_w = rl_f(tab.wne, v), tsw_w = rl_f(tab.wsw, v), tse_w = rl_f(tab.wse, v);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          d0[c] = gpn_bilerp(tnw[0][c], tne[0][c], tsw[0][c], tse[0][c], t);
-          d1[c] = gpn_bilerp(tnw[1][c], tne[1][c], tsw[1][c], tse[1][c], t);
+          d0[c] = gpn_bilerp4(tp[0][c], tp[2][c], tp[4][c], tp[6][c], tnw_w, tne_w, tsw_w, tse_w);
+          d1[c] = gpn_bilerp4(tp[1][c], tp[3][c], tp[5][c], tp[7][c], tnw_w, tne_w, tsw_w, tse_w);
         }
+        // next pair: the next live view of this sample, else the first live view of the next one
+        if (live) fetch_taps(tab, __builtin_ctz(live));
+        else if (live_n) fetch_taps(tab_next, __builtin_ctz(live_n));
       }
       float w3 = w3u, w2 = w2u;
       if (vis != 0) {
-        w3 = 0.f, w2 = 0.f;
+        // logits of this lane's channel group in all layers: attn_fc[2] row . hidden + bias (:66-70),
+        // two layers per packed fma; softmax weight = 2^(logit - lse) in log2 units
+        const float* hp = sH[wave];
+        f2 w3p = (f2){0.f, 0.f}, w2p = (f2){0.f, 0.f};
 #pragma unroll
-        for (int l = 0; l < DEPTH; ++l) {
-          const float at = __expf(lg[l] - lse[l]);
-          w3 += at;
-          w2 += ab[l] * at;
+        for (int p = 0; p < LP; ++p) {
+          f2 lg = bl[p];
+#pragma unroll
+          for (int k = 0; k < 8; k += 2) {
+            const f4 h = ld4(hp + (p * 8 + k) * 2);  // (k, 2p) (k, 2p+1) (k+1, 2p) (k+1, 2p+1)
+            lg = a2w[p][k] * h.lo + lg;
+            lg = a2w[p][k + 1] * h.hi + lg;
+          }
+          f2 at;
+          at.x = __builtin_amdgcn_exp2f(lg.x);
+          at.y = (2 * p + 1 < DEPTH) ? __builtin_amdgcn_exp2f(lg.y) : 0.0f;
+          w3p = w3p + at;
+          w2p = ab[p] * at + w2p;
         }
+        w3 = w3p.x + w3p.y, w2 = w2p.x + w2p.y;
       }
       acc3a = acc3a + d0 * f4_splat(w3);
       acc3b = acc3b + d1 * f4_splat(w3);
@@ -1522,7 +1601,7 @@ extern "C" int gpn_view_fold(const gpn_view_layer_t* L, float* out, gpn_stream_t
 
 extern "C" int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const float* feat,
                              const float* ray_diff, const float* mask, const int32_t* perm, int N,
-                             int V, float* q_out, float* logits, int logits_ld, float* stats,
+                             int V, float* q_out, float* hidden, int hidden_ld, float* stats,
                              int stats_ld, gpn_stream_t stream) {
   if (N == 0) return GPN_OK;  // empty batch (pointers may be null)
   GPN_REQUIRE(L && q_in && feat && ray_diff && mask && q_out, "gpn_view_attn: null pointer");
@@ -1534,10 +1613,10 @@ extern "C" int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const
                   L->attn_norm_b, "gpn_view_attn: null weight");
   GPN_REQUIRE(N >= 0 && V >= 1 && V <= GPN_MAX_VIEWS, "gpn_view_attn: need 1<=V<=%d (got %d)",
               GPN_MAX_VIEWS, V);
-  GPN_REQUIRE(aligned16(q_in) && aligned16(feat) && aligned16(q_out) && aligned16(logits) &&
+  GPN_REQUIRE(aligned16(q_in) && aligned16(feat) && aligned16(q_out) && aligned16(hidden) &&
                   aligned16(stats), "gpn_view_attn: tensors must be 16-byte aligned");
-  GPN_REQUIRE(!logits || (logits_ld >= C64 && logits_ld % 4 == 0),
-              "gpn_view_attn: logits_ld must be a multiple of 4 and >= %d (got %d)", C64, logits_ld);
+  GPN_REQUIRE(!hidden || (hidden_ld >= 8 && hidden_ld % 4 == 0),
+              "gpn_view_attn: hidden_ld must be a multiple of 4 and >= 8 (got %d)", hidden_ld);
   GPN_REQUIRE(!stats || (stats_ld >= C64 && stats_ld % 4 == 0),
               "gpn_view_attn: stats_ld must be a multiple of 4 and >= %d (got %d)", C64, stats_ld);
   const bool spl = gpn_precision() == GPN_PREC_BF16X3;
@@ -1554,13 +1633,13 @@ extern "C" int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const
   hipStream_t st = (hipStream_t)stream;
   if (fold)
     hipLaunchKernelGGL((k_view_attn<true, true>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
-                       (long long)N, V, q_out, logits, logits_ld, stats, stats_ld);
+                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld);
   else if (spl)
     hipLaunchKernelGGL((k_view_attn<true, false>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
-                       (long long)N, V, q_out, logits, logits_ld, stats, stats_ld);
+                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld);
   else
     hipLaunchKernelGGL((k_view_attn<false, false>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
-                       (long long)N, V, q_out, logits, logits_ld, stats, stats_ld);
+                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld);
   GPN_LAUNCH_CHECK("k_view_attn");
   return GPN_OK;
 }
@@ -1675,7 +1754,9 @@ extern "C" int gpn_sem_aggregate(const gpn_sem_args_t* a, gpn_stream_t stream) {
   GPN_REQUIRE(a->R >= 0 && a->S >= 1 && a->V >= 1 && a->V <= GPN_MAX_VIEWS && a->depth >= 1 &&
                   a->depth <= GPN_MAX_DEPTH, "gpn_sem_aggregate: bad shape");
   GPN_REQUIRE(a->mask && a->pre, "gpn_sem_aggregate: null pointer");
-  GPN_REQUIRE(a->logits && a->stats && a->abar, "gpn_sem_aggregate: null logits / stats / abar");
+  GPN_REQUIRE(a->hidden && a->stats && a->abar, "gpn_sem_aggregate: null hidden / stats / abar");
+  for (int l = 0; l < a->depth; ++l)
+    GPN_REQUIRE(a->attn2_w[l], "gpn_sem_aggregate: attn2_w[%d] is null", l);
   GPN_REQUIRE((a->deep_dense != nullptr) != (a->deep_map != nullptr),
               "gpn_sem_aggregate: exactly one of deep_dense / deep_map must be given");
   if (a->deep_map) {
@@ -1735,7 +1816,7 @@ extern "C" int gpn_heads(const gpn_gnt_weights_t* W, const float* q, const float
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct GntWs {
-  size_t emb, feat, q, logits, stats, abar, weights, pre, perm, vis_scratch, total;
+  size_t emb, feat, q, hidden, stats, abar, weights, pre, perm, vis_scratch, total;
 };
 static GntWs gnt_ws_layout(int R, int S, int V, int depth) {
   const size_t N = (size_t)R * S, f = sizeof(float);
@@ -1744,7 +1825,7 @@ static GntWs gnt_ws_layout(int R, int S, int V, int depth) {
   w.emb = o, o += align_up(N * GPN_EMB * f);
   w.feat = o, o += align_up(N * V * C64 * f);
   w.q = o, o += align_up(N * C64 * f);
-  w.logits = o, o += align_up(N * V * depth * C64 * f);  // [N,V,depth,64]
+  w.hidden = o, o += align_up(N * V * depth * 8 * f);    // [N,V,depth,8]
   w.stats = o, o += align_up(N * depth * C64 * f);        // [N,depth,64]
   w.abar = o, o += align_up(N * depth * 4 * f);           // [R,S,depth,4]
   w.weights = o, o += align_up(N * f);
@@ -1795,12 +1876,12 @@ extern "C" int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat
     return rc;
   for (int l = 0; l < D; ++l) {
     // side outputs for the semantic aggregation, interleaved over the layers
-    float* lg = sem ? reinterpret_cast<float*>(ws + L.logits) + l * C64 : nullptr;
+    float* hd = sem ? reinterpret_cast<float*>(ws + L.hidden) + l * 8 : nullptr;
     float* st = sem ? reinterpret_cast<float*>(ws + L.stats) + l * C64 : nullptr;
     float* ab = sem ? reinterpret_cast<float*>(ws + L.abar) + l * 4 : nullptr;
     const gpn_view_layer_t* vl = &W->view[l];
     const gpn_ray_layer_t* rl = &W->ray[l];
-    if ((rc = gpn_view_attn(vl, q, feat, ray_diff, mask, perm, (int)N, V, q, lg, D * C64, st, D * C64,
+    if ((rc = gpn_view_attn(vl, q, feat, ray_diff, mask, perm, (int)N, V, q, hd, D * 8, st, D * C64,
                             stream)))
       return rc;
     if ((rc = gpn_ff(vl->ff_norm_w, vl->ff_norm_b, &vl->ff1, &vl->ff2, q, (int)N, q, stream))) return rc;
@@ -1811,7 +1892,8 @@ extern "C" int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat
   }
   if (sem) {
     sem->R = R, sem->S = S, sem->V = V, sem->depth = D;
-    sem->logits = reinterpret_cast<float*>(ws + L.logits);
+    sem->hidden = reinterpret_cast<float*>(ws + L.hidden);
+    for (int l = 0; l < D; ++l) sem->attn2_w[l] = W->view[l].attn2.w, sem->attn2_b[l] = W->view[l].attn2.b;
     sem->stats = reinterpret_cast<float*>(ws + L.stats);
     sem->abar = reinterpret_cast<float*>(ws + L.abar);
     sem->mask = mask;

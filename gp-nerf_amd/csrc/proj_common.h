@@ -82,3 +82,15 @@ __device__ __forceinline__ float gpn_bilerp(float vnw, float vne, float vsw, flo
   o = __builtin_fmaf(vse, t.se, o);
   return o;
 }
+
+// Same accumulation with the four weights passed separately (a zero weight stands for an
+// out-of-map tap: value * 0 contributes the same exact zero as grid_sample's zero padding).
+__device__ __forceinline__ float gpn_bilerp4(float vnw, float vne, float vsw, float vse, float wnw,
+                                             float wne, float wsw, float wse) {
+#pragma clang fp contract(off)
+  float o = vnw * wnw;
+  o = __builtin_fmaf(vne, wne, o);
+  o = __builtin_fmaf(vsw, wsw, o);
+  o = __builtin_fmaf(vse, wse, o);
+  return o;
+}

@@ -177,16 +177,20 @@ int gpn_rgbfeat(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* r
 /* Attention part of Transformer2D (attn_norm, Attention2D, residual), transformer_network.py:74-88
  * and :107-112.  q_in [N,C], feat [N,V,C], ray_diff [N,V,4], mask [N,V] -> q_out [N,C];
  * perm [2N] (or NULL): processing order + visibility bits from gpn_vis_order.
- * logits: C pre-softmax attention values per VISIBLE (point, view) pair (mask != 0; entries of
+ * hidden: the C/8 = 8 post-ReLU hidden values of attn_fc (transformer_network.py:66-70, the
+ * 64 -> 8 -> 64 MLP in front of the softmax) per VISIBLE (point, view) pair (mask != 0; entries of
  * masked pairs are left unwritten: their softmax weight is exactly 0, or exactly 1/V when the
- * point has no visible view at all), the row of pair (n, v) starting at logits[(n*V+v)*logits_ld];
+ * point has no visible view at all), the row of pair (n, v) starting at hidden[(n*V+v)*hidden_ld].
+ * The C pre-softmax logits of the pair are attn_fc[2].weight . hidden + attn_fc[2].bias: storing
+ * their 8-value pre-image instead of the 64 logits cuts this side channel (the largest stream of
+ * the whole forward pass) eightfold; gpn_sem_aggregate rebuilds the logits from it.
  * stats: log-sum-exp over the views, C values per point, row n starting at stats[n*stats_ld], so
- * that the per-channel view softmax of line :84 is exp(logit - lse).  logits_ld >= C and
+ * that the per-channel view softmax of line :84 is exp(logit - lse).  hidden_ld >= 8 and
  * stats_ld >= C (multiples of 4) let the caller interleave the layers (see gpn_sem_args_t);
- * logits/stats may be NULL. */
+ * hidden/stats may be NULL. */
 int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const float* feat,
                   const float* ray_diff, const float* mask, const int32_t* perm, int N, int V,
-                  float* q_out, float* logits, int logits_ld, float* stats, int stats_ld,
+                  float* q_out, float* hidden, int hidden_ld, float* stats, int stats_ld,
                   gpn_stream_t stream);
 
 /* No counterpart in the reference (weight preprocessing for gpn_view_attn, once per model): folds the
@@ -228,7 +232,7 @@ typedef struct {
   int R, S, V, depth;
   /* per-layer side outputs of gpn_view_attn / gpn_ray_attn, interleaved over the layers so that
    * everything one (sample, view) needs is contiguous: */
-  const float* logits;                /* [N,V,depth,C]  (layer l: logits + l*C,  ld = depth*C)  */
+  const float* hidden;                /* [N,V,depth,8]  (layer l: hidden + l*8,  ld = depth*8)  */
   const float* stats;                 /* [N,depth,C]    (layer l: stats + l*C,   ld = depth*C)  */
   const float* abar;                  /* [R,S,depth,4]  (layer l: abar + l*4,    ld = depth*4)  */
   const float* mask;                  /* [N,V] */
@@ -242,6 +246,9 @@ typedef struct {
   float img_h, img_w;
   float* sem3d;                       /* out [N,512] = sem_feat_3d, or NULL */
   float* pre;                         /* out [R,512] = mean_s sum_l ray_sem_l (adaptor input) */
+  /* attn_fc[2] of every view layer (weight [C,8] row-major, bias [C]): logits = W . hidden + b */
+  const float* attn2_w[GPN_MAX_DEPTH];
+  const float* attn2_b[GPN_MAX_DEPTH];
 } gpn_sem_args_t;
 
 /* Deep-semantic aggregation of Attention2D (:90), Attention (:180-184) and GNT.forward (:335-336)
@@ -257,7 +264,7 @@ int gpn_heads(const gpn_gnt_weights_t* W, const float* q, const float* weights, 
 
 /* Whole GNT.forward (transformer_network.py:295-338) on a caller-provided workspace.
  * Inputs as gpn_rgbfeat / gpn_view_attn; `sem` carries the deep-semantic source and outputs
- * (its logits/stats/abar/mask/R/S/V/depth fields are filled in by this call); sem may be NULL. */
+ * (its hidden/stats/abar/mask/R/S/V/depth/attn2_* fields are filled in by this call); sem may be NULL. */
 size_t gpn_gnt_workspace_bytes(int R, int S, int V, int depth);
 int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat, const float* ray_diff,
                     const float* mask, const float* pts, const float* ray_d, const float* z_vals,

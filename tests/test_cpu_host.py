@@ -57,13 +57,13 @@ def test_argument_errors_come_back_as_messages():
     assert rc == 0  # empty batch is a no-op
     # argument checks run before any HIP call, so they are testable without a GPU
     assert L.gpn_view_fold(None, None, None) == -1 and b"null pointer" in L.gpn_last_error()
-    assert L.gpn_view_attn(None, None, None, None, None, None, 16, 10, None, None, 64, None, 64, None) == -1
+    assert L.gpn_view_attn(None, None, None, None, None, None, 16, 10, None, None, 8, None, 64, None) == -1
     assert b"null pointer" in L.gpn_last_error()
     assert L.gpn_get_precision() in (0, 1)
     before = L.gpn_get_precision()
     assert L.gpn_set_precision(7) == -1 and b"unknown mode" in L.gpn_last_error()
     assert L.gpn_get_precision() == before
-    assert L.gpn_gnt_workspace_bytes(4096, 64, 10, 8) > 4096 * 64 * 10 * 8 * 64 * 4  # holds the logits
+    assert L.gpn_gnt_workspace_bytes(4096, 64, 10, 8) > 4096 * 64 * 10 * (8 * 8 + 64) * 4  # hidden side channel + feat
     assert L.gpn_gnt_workspace_bytes(0, 0, 0, 0) == 0
     with pytest.raises(RuntimeError, match="gpn_sample_along_ray failed"):
         _lib.check(L.gpn_sample_along_ray(None, None, 1.0, 2.0, 4, 8, 0, None, None, None, None),

@@ -76,6 +76,13 @@ def dec_feat(buf, prec):
     return t.reshape(lead + (64,))
 
 
+def logits_of(hid, vl_mod):
+    """gpn_view_attn's side output (8 hidden values per visible pair) -> the 64 pre-softmax logits:
+    attn_fc[2].weight . hidden + attn_fc[2].bias (reference transformer_network.py:66-70)."""
+    w, b = vl_mod.attn.attn_fc[2].weight, vl_mod.attn.attn_fc[2].bias
+    return hid @ w.t() + b
+
+
 def rel(a, b):
     """max |a-b| relative to the scale of b (at least 1)."""
     a = a.detach().float().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
@@ -303,9 +310,9 @@ def test_gnt_stages(dev, net, prec, S):
     emb_ref = f(want)
     for l in (0, 1, 7):
         q_in = f((rec["q0"] if l == 0 else rec["q_ray"][l - 1]).reshape(N, 64))
-        qo, lg, stt = e(N, 64), e(N, V, 64), e(N, 64)
+        qo, hd, stt = e(N, 64), torch.zeros(N, V, 8, device=dev), e(N, 64)
         _lib.check(L.gpn_view_attn(C.byref(W.view[l]), _lib.ptr(q_in), _lib.ptr(feat_ref), _lib.ptr(rd),
-                                   _lib.ptr(mk), None, N, V, _lib.ptr(qo), _lib.ptr(lg), 64,
+                                   _lib.ptr(mk), None, N, V, _lib.ptr(qo), _lib.ptr(hd), 8,
                                    _lib.ptr(stt), 64, st), "view")
         errs["view_attn%d" % l] = rel(qo, rec["q_view_attn"][l].reshape(N, 64))
         if l == 0:  # the same layer without the folded weight products (reference operation order)
@@ -329,14 +336,15 @@ def test_gnt_stages(dev, net, prec, S):
         assert bool((cost[1:] <= cost[:-1]).all()), "perm is not ordered by decreasing cost class"
         runs = int((key[1:] != key[:-1]).sum()) + 1
         assert runs == int(torch.unique(key).numel()), "a visibility pattern is split across bins"
-        qo2, lg2, stt2 = e(N, 64), torch.zeros_like(lg), e(N, 64)
-        lg.masked_fill_(mk.reshape(N, V, 1) == 0, 0.0)  # unwritten (masked) entries -> 0 on both sides
+        qo2, hd2, stt2 = e(N, 64), torch.zeros_like(hd), e(N, 64)
+        # (entries of masked pairs are never written: they stay 0 on both sides)
         _lib.check(L.gpn_view_attn(C.byref(W.view[l]), _lib.ptr(q_in), _lib.ptr(feat_ref), _lib.ptr(rd),
-                                   _lib.ptr(mk), _lib.ptr(perm2), N, V, _lib.ptr(qo2), _lib.ptr(lg2), 64,
+                                   _lib.ptr(mk), _lib.ptr(perm2), N, V, _lib.ptr(qo2), _lib.ptr(hd2), 8,
                                    _lib.ptr(stt2), 64, st), "view-perm")
-        lg2.masked_fill_(mk.reshape(N, V, 1) == 0, 0.0)
-        assert torch.equal(qo, qo2) and torch.equal(stt, stt2) and torch.equal(lg, lg2), \
+        assert torch.equal(qo, qo2) and torch.equal(stt, stt2) and torch.equal(hd, hd2), \
             "visibility-sorted order changed the results"
+        assert bool((hd[(mk.reshape(N, V) == 0)] == 0).all()), "a masked pair's hidden row was written"
+        lg = logits_of(hd, net.view_crosstrans[l])
         # logits of masked pairs are never written: weight 0, or 1/V for an all-masked point
         vis = mk.reshape(N, V, 1) != 0
         attn = torch.where(vis, torch.exp(lg - stt[:, None]),
@@ -412,13 +420,14 @@ def test_gnt_stages_many_tiles(dev, net, prec):
     assert torch.equal(torch.sort(perm2[:N].long())[0].cpu(), torch.arange(N))
     outs = []
     for pm in (None, perm2):
-        qo, lg, stt = e(N, 64), torch.zeros(N, V, 64, device=dev), e(N, 64)
+        qo, hd, stt = e(N, 64), torch.zeros(N, V, 8, device=dev), e(N, 64)
         _lib.check(L.gpn_view_attn(C.byref(W.view[0]), _lib.ptr(qd), _lib.ptr(fd), _lib.ptr(rd), _lib.ptr(mk),
                                    _lib.ptr(pm) if pm is not None else None, N, V, _lib.ptr(qo),
-                                   _lib.ptr(lg), 64, _lib.ptr(stt), 64, st), "view")
-        outs.append((qo, lg, stt))
+                                   _lib.ptr(hd), 8, _lib.ptr(stt), 64, st), "view")
+        outs.append((qo, hd, stt))
     assert all(torch.equal(a_, b_) for a_, b_ in zip(*outs)), "visibility-sorted order changed the results"
-    qo, lg, stt = outs[0]
+    qo, hd, stt = outs[0]
+    lg = logits_of(hd, net.view_crosstrans[0])
     errs["view_attn"] = rel(qo, want_q)
     vis = mk.reshape(N, V, 1) != 0
     a2 = torch.where(vis, torch.exp(lg - stt[:, None]), torch.zeros_like(lg))

@@ -34,7 +34,7 @@ rgb_feat = rgb_feat.reshape(N, V, -1).contiguous()
 _lib.check(L.gpn_rgbfeat(C.byref(W.rgbfeat0), C.byref(W.rgbfeat2), _lib.ptr(rgb_feat), N, V, rgb_feat.shape[-1],
                          _lib.ptr(feat), _lib.ptr(q), st), "rgbfeat")
 qo = torch.empty_like(q)
-logits = torch.empty(N, V, 8, 64, device=dev)
+logits = torch.empty(N, V, 8, 8, device=dev)  # hidden side channel [N,V,depth,8]
 stats = torch.empty(N, 8, 64, device=dev)
 perm = torch.empty(2 * N, dtype=torch.int32, device=dev)
 scratch = torch.empty(L.gpn_vis_order_scratch_bytes(), dtype=torch.uint8, device=dev)
@@ -55,14 +55,14 @@ def timeit(fn, reps=20):
     return a.elapsed_time(b) / reps * 1e3
 
 
-def run(m, use_perm, side, ld=8 * 64):
+def run(m, use_perm, side, ld=8 * 64, hld=8 * 8):
     if use_perm:
         _lib.check(L.gpn_vis_order(_lib.ptr(m), N, V, _lib.ptr(perm), _lib.ptr(scratch), st), "vis")
     p = _lib.ptr(perm) if use_perm else None
     lg = _lib.ptr(logits) if side else None
     sp = _lib.ptr(stats) if side else None
     return timeit(lambda: _lib.check(L.gpn_view_attn(C.byref(vl), _lib.ptr(q), _lib.ptr(feat), _lib.ptr(ray_diff),
-                                                     _lib.ptr(m), p, N, V, _lib.ptr(qo), lg, ld, sp, ld, st), "va"))
+                                                     _lib.ptr(m), p, N, V, _lib.ptr(qo), lg, hld, sp, ld, st), "va"))
 
 
 ones = torch.ones_like(mask)
@@ -79,5 +79,5 @@ for name, m, up, side in (("real masks, sorted, side outputs", mask, True, True)
     t = run(m, up, side)
     print("%-45s %8.1f us   %.1f ns per visible pair-tile(16)" % (name, t, t * 1e3 / (pairs / 16)), flush=True)
 
-print("dense side outputs (ld=64), real masks sorted: %.1f us" % run(mask, True, True, 64))
-print("dense side outputs (ld=64), all visible sorted: %.1f us" % run(ones, True, True, 64))
+print("dense side outputs (ld=64/8), real masks sorted: %.1f us" % run(mask, True, True, 64, 8))
+print("dense side outputs (ld=64/8), all visible sorted: %.1f us" % run(ones, True, True, 64, 8))

@@ -1272,7 +1272,10 @@ k_sem(gpn_sem_args_t a) {
   const int r = blk * SEM_RAYS + wave;
   const bool rvalid = r < a.R;
   const int rc = rvalid ? r : a.R - 1;
-  const int c8 = lane * 8, head = lane >> 4;  // lane == channel group
+  // lane == channel group (8 channels) for the attention weights; the 512-channel rows themselves
+  // are read and written as two fully coalesced 1 KB halves: lane holds channels 4*lane..+3 and
+  // 256 + 4*lane..+3, whose groups are lane/2 and 32 + lane/2 (weights fetched from those lanes)
+  const int c4 = lane * 4, head = lane >> 4;
   f4 acc2a = f4_zero(), acc2b = f4_zero();
   const size_t rs = (size_t)a.deep_w * GPN_SEM;
   const unsigned urs = (unsigned)rs;  // one map is < 2^31 floats: 32-bit element offsets inside a view
@@ -1326,9 +1329,9 @@ k_sem(gpn_sem_args_t a) {
   f4 tp[8];
   auto fetch_taps = [&](const TapTab& t_, int v_) {
     const unsigned s00 = rl_u(t_.o00, v_), s01 = rl_u(t_.o01, v_), s10 = rl_u(t_.o10, v_), s11 = rl_u(t_.o11, v_);
-    const float* dm = a.deep_map + (size_t)v_ * a.deep_h * rs + (unsigned)c8;
-    tp[0] = ld4(dm + s00), tp[1] = ld4(dm + s00 + 4), tp[2] = ld4(dm + s01), tp[3] = ld4(dm + s01 + 4);
-    tp[4] = ld4(dm + s10), tp[5] = ld4(dm + s10 + 4), tp[6] = ld4(dm + s11), tp[7] = ld4(dm + s11 + 4);
+    const float* dm = a.deep_map + (size_t)v_ * a.deep_h * rs + (unsigned)c4;
+    tp[0] = ld4(dm + s00), tp[1] = ld4(dm + s00 + 256), tp[2] = ld4(dm + s01), tp[3] = ld4(dm + s01 + 256);
+    tp[4] = ld4(dm + s10), tp[5] = ld4(dm + s10 + 256), tp[6] = ld4(dm + s11), tp[7] = ld4(dm + s11 + 256);
   };
   auto live_of_mask = [&](float m_) {
     const unsigned vis_ = (unsigned)__ballot(m_ != 0.0f);
@@ -1395,8 +1398,8 @@ k_sem(gpn_sem_args_t a) {
       f4 d0, d1;
       if (dense) {
         const float* dd = a.deep_dense + (n * V + v) * GPN_SEM;
-        d0 = ld4(dd + (unsigned)c8);
-        d1 = ld4(dd + (unsigned)(c8 + 4));
+        d0 = ld4(dd + (unsigned)c4);
+        d1 = ld4(dd + (unsigned)(c4 + 256));
       } else {
         // this view's tap weights: wave-uniform (scalar registers); out-of-map taps carry weight 0
         const float tnw_w = rl_f(tab.wnw, v), tne_w = rl_f(tab.wne, v), tsw_w = rl_f(tab.wsw, v), tse_w = rl_f(tab.wse, v);
@@ -1432,20 +1435,25 @@ k_sem(gpn_sem_args_t a) {
         }
         w3 = w3p.x + w3p.y, w2 = w2p.x + w2p.y;
       }
-      acc3a = acc3a + d0 * f4_splat(w3);
-      acc3b = acc3b + d1 * f4_splat(w3);
-      acc2a = acc2a + d0 * f4_splat(w2);
-      acc2b = acc2b + d1 * f4_splat(w2);
+      // weights of the two channel groups this lane's channels belong to
+      const float w3A = __shfl(w3, lane >> 1), w3B = __shfl(w3, 32 + (lane >> 1));
+      const float w2A = __shfl(w2, lane >> 1), w2B = __shfl(w2, 32 + (lane >> 1));
+      acc3a = acc3a + d0 * f4_splat(w3A);
+      acc3b = acc3b + d1 * f4_splat(w3B);
+      acc2a = acc2a + d0 * f4_splat(w2A);
+      acc2b = acc2b + d1 * f4_splat(w2B);
     }
     if (a.sem3d != nullptr && rvalid) {
-      __builtin_nontemporal_store(acc3a, reinterpret_cast<f4*>(a.sem3d + n * GPN_SEM + c8));
-      __builtin_nontemporal_store(acc3b, reinterpret_cast<f4*>(a.sem3d + n * GPN_SEM + c8 + 4));
+      __builtin_nontemporal_store(acc3a, reinterpret_cast<f4*>(a.sem3d + n * GPN_SEM + c4));
+      __builtin_nontemporal_store(acc3b, reinterpret_cast<f4*>(a.sem3d + n * GPN_SEM + c4 + 256));
     }
+#ifndef SEM_NO_SYNC
     __syncthreads();  // keep the 8 rays of the group on the same sample (cache locality only)
+#endif
   }
   if (rvalid) {
-    st4(a.pre + (size_t)r * GPN_SEM + c8, acc2a);
-    st4(a.pre + (size_t)r * GPN_SEM + c8 + 4, acc2b);
+    st4(a.pre + (size_t)r * GPN_SEM + c4, acc2a);
+    st4(a.pre + (size_t)r * GPN_SEM + c4 + 256, acc2b);
   }
 }
 

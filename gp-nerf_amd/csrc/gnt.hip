@@ -153,7 +153,7 @@ k_rgbfeat(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ rgb_feat
       lin<SPL, 3, 4>(W0, RF_LD0, x, h, lane);
 #pragma unroll
       for (int M = 0; M < 4; ++M) {
-        h[M] = f4_relu(h[M]);
+        h[M] = f4_relu_t<SPL>(h[M]);
         y[M] = ld4(b2 + 16 * M + 4 * g);
       }
       lin<SPL, 4, 4>(W2, LDW, h, y, lane);
@@ -627,7 +627,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
           a[M] = ld4(L.bA2 + 16 * M + 4 * g);
         }
         // pos hidden layer: 4 -> 8 (ReLU), one fp32 MFMA
-        f4 ph = f4_relu(mfma16(p0w, rd, ld4(L.bP0 + 4 * g)));
+        f4 ph = f4_relu_t<SPL>(mfma16(p0w, rd, ld4(L.bP0 + 4 * g)));
         f4 ah;  // post-ReLU hidden layer of attn_fc: rows 4g..4g+3 of the (zero-padded) 16
         if constexpr (FOLD) {
           // v + pos = (Wv Wk) f + P2 h + b ; attn hidden = (A0 Wk) f + (A0 P2) h + aq : every product
@@ -640,7 +640,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
           lin_Sx<1, 4>(L.P2, xs + 2, vp, lane);
           ah = aq;
           lin_Sx<6, 1>(L.AF, xs, &ah, lane);
-          ah = f4_relu(ah);
+          ah = f4_relu_t<SPL>(ah);
           lin<SPL, 1, 4>(L.A2, VA_LD8, &ah, a, lane);
         } else {
           f4 k[4];
@@ -667,7 +667,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
           for (int M = 0; M < 4; ++M) vp[M] = vp[M] + pos[M];
           ah = ld4(L.bA0 + 4 * g);
           lin<SPL, 4, 1>(L.A0, LDW, ain, &ah, lane);
-          ah = f4_relu(ah);
+          ah = f4_relu_t<SPL>(ah);
           lin<SPL, 1, 4>(L.A2, VA_LD8, &ah, a, lane);
         }
 const bool vis_v = MODE == VM_HOMOG || ((vis >> v) & 1u) != 0;
@@ -872,8 +872,8 @@ k_ff(const float* __restrict__ norm_w, const float* __restrict__ norm_b, gpn_lin
         XS hs[NTL][2];
 #pragma unroll
         for (int t = 0; t < NTL; ++t) {
-          hs[t][0] = split8(f4_relu(h[t][0]), f4_relu(h[t][1]));
-          hs[t][1] = split8(f4_relu(h[t][2]), f4_relu(h[t][3]));
+          hs[t][0] = split8(f4_relu_t<true>(h[t][0]), f4_relu_t<true>(h[t][1]));
+          hs[t][1] = split8(f4_relu_t<true>(h[t][2]), f4_relu_t<true>(h[t][3]));
         }
         lin_S2<8, 2, 4, NTL>(w2p + (2 * c) * 128, hs, y);      // all 64 rows, hidden 64c..64c+63
       }
@@ -953,7 +953,7 @@ k_qpos(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ q_in,
     lin<SPL, 12, 4>(W0, QP_LD0, x, h, lane);
 #pragma unroll
     for (int M = 0; M < 4; ++M) {
-      h[M] = f4_relu(h[M]);
+      h[M] = f4_relu_t<SPL>(h[M]);
       y[M] = ld4(b2 + 16 * M + 4 * g);
     }
     lin<SPL, 4, 4>(W2, LDW, h, y, lane);

@@ -32,9 +32,26 @@ __device__ __forceinline__ f4 f4_splat(float v) { return (f4){v, v, v, v}; }
 // max without the canonicalising pre-pass fmaxf gets (operands are never NaN here)
 __device__ __forceinline__ float max_nc(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
 __device__ __forceinline__ float max3_nc(float a, float b, float c) { return max_nc(max_nc(a, b), c); }
-// max(x, 0) as one v_med3_f32 (fmaxf costs a canonicalising v_max first)
+// max(x, 0): fmaxf / fmed3 make hipcc put a canonicalising v_max_f32 x, x in front of the real one
+// (256 of the 921 vector instructions of a split-mode k_ff iteration were those pairs).
+// f4_relu_t<true> is the single-instruction form; its result must be consumed by a VECTOR instruction (the
+// operand split of the bf16x3 mode): hipcc does not insert the wait states an MFMA reading a
+// register written inside an asm statement needs.  relu1 is the safe form for MFMA consumers.
 __device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
 __device__ __forceinline__ f4 f4_relu(f4 v) { return (f4){relu1(v.x), relu1(v.y), relu1(v.z), relu1(v.w)}; }
+// VALU_CONSUMER = the result feeds the bf16x3 operand split (never an MFMA directly)
+template <bool VALU_CONSUMER>
+__device__ __forceinline__ f4 f4_relu_t(f4 v) {
+  if constexpr (VALU_CONSUMER) {
+    // in place, one statement per f4; the leading s_nop covers a store still reading these registers
+    // (hipcc's hazard handling does not look inside asm statements)
+    asm("s_nop 1\n\tv_max_f32 %0, 0, %0\n\tv_max_f32 %1, 0, %1\n\tv_max_f32 %2, 0, %2\n\tv_max_f32 %3, 0, %3"
+        : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+    return v;
+  } else {
+    return f4_relu(v);
+  }
+}
 __device__ __forceinline__ f4 f4_max(f4 a, f4 b) {
   return (f4){max_nc(a.x, b.x), max_nc(a.y, b.y), max_nc(a.z, b.z), max_nc(a.w, b.w)};
 }

@@ -1236,7 +1236,10 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
 // exactly 0 and are skipped; a sample with no visible view has the uniform weight 1/V in every layer.
 #define SEM_RAYS 8
 #ifndef SEM_WAVES_PER_SIMD
-#define SEM_WAVES_PER_SIMD 2
+#define SEM_WAVES_PER_SIMD 4
+#endif
+#ifndef SEM_PREFETCH
+#define SEM_PREFETCH 0  // 1: taps of the next (sample, view) in flight (+40 VGPRs: measured slower than 4 waves per SIMD)
 #endif
 typedef const __attribute__((address_space(4))) float* sem_cfp;
 __device__ __forceinline__ float rl_f(float v, int l) {
@@ -1252,6 +1255,7 @@ k_sem(gpn_sem_args_t a) {
   constexpr int LP = (DEPTH + 1) / 2;  // layers are processed in pairs (v_pk_fma_f32)
   __shared__ float sP[GPN_MAX_VIEWS * 12];
   __shared__ __attribute__((aligned(16))) float sH[SEM_RAYS][LP * 16];
+  __shared__ __attribute__((aligned(16))) float sW[LP * 4 * 64 * 4];
   const int tid = threadIdx.x, lane = tid & 63;
   // the wave index (hence the ray and every per-sample address) is wave-uniform: keep it in SGPRs
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1285,7 +1289,9 @@ k_sem(gpn_sem_args_t a) {
   // attn_fc[2] of every layer: this lane's row (its channel group) of the [64,8] weight and its
   // bias, scaled by log2(e) so that the softmax weight is a bare v_exp_f32; layers l = 2p, 2p+1
   // sit in the two halves of an f2 (one v_pk_fma_f32 per hidden value and layer pair)
-  f2 a2w[LP][8], a2b[LP];
+  // (weights live in LDS, one 16-byte unit per lane, layer pair and pair of hidden values:
+  // (w[2p][k], w[2p+1][k], w[2p][k+1], w[2p+1][k+1]); 72 registers fewer = twice the waves per SIMD)
+  f2 a2b[LP];
 #pragma unroll
   for (int l = 0; l < 2 * LP; ++l) {
     f4 w0 = f4_zero(), w1 = f4_zero();
@@ -1294,10 +1300,16 @@ k_sem(gpn_sem_args_t a) {
       w0 = ld4(a.attn2_w[l] + lane * 8), w1 = ld4(a.attn2_w[l] + lane * 8 + 4);
       b = a.attn2_b[l] ? a.attn2_b[l][lane] : 0.0f;
     }
+    if (wave == 0) {  // one wave fills the image (every wave would write the same values)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) a2w[l >> 1][k][l & 1] = w0[k] * LOG2E_F, a2w[l >> 1][4 + k][l & 1] = w1[k] * LOG2E_F;
+      for (int k = 0; k < 4; ++k) {
+        sW[(((l >> 1) * 4 + (k >> 1)) * 64 + lane) * 4 + (k & 1) * 2 + (l & 1)] = w0[k] * LOG2E_F;
+        sW[(((l >> 1) * 4 + 2 + (k >> 1)) * 64 + lane) * 4 + (k & 1) * 2 + (l & 1)] = w1[k] * LOG2E_F;
+      }
+    }
     a2b[l >> 1][l & 1] = b;
   }
+  __syncthreads();
   // hidden value i = 8 l + k of a pair is parked at LDS slot ((l>>1)*8 + k)*2 + (l&1): the two
   // layers of a pair side by side, read back 4 floats (2 hidden values x 2 layers) at a time
   const int hslot = lane < DEPTH * 8 ? ((lane >> 4) * 8 + (lane & 7)) * 2 + ((lane >> 3) & 1) : 0;
@@ -1342,7 +1354,7 @@ k_sem(gpn_sem_args_t a) {
   TapTab tab_next = tap_table((size_t)rc * S);
 #pragma unroll
   for (int k = 0; k < 8; ++k) tp[k] = f4_zero();
-  if (!dense) {
+  if (!dense && SEM_PREFETCH) {
     const unsigned v0 = live_of_mask(mv_next);
     fetch_taps(tab_next, __builtin_ctz(v0 != 0 ? v0 : all_views));
   }
@@ -1403,14 +1415,17 @@ k_sem(gpn_sem_args_t a) {
       } else {
         // this view's tap weights: wave-uniform (scalar registers); out-of-map taps carry weight 0
         const float tnw_w = rl_f(tab.wnw, v), tne_w = rl_f(tab.wne, v), tsw_w = rl_f(tab.wsw, v), tse_w = rl_f(tab.wse, v);
+        if (!SEM_PREFETCH) fetch_taps(tab, v);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           d0[c] = gpn_bilerp4(tp[0][c], tp[2][c], tp[4][c], tp[6][c], tnw_w, tne_w, tsw_w, tse_w);
           d1[c] = gpn_bilerp4(tp[1][c], tp[3][c], tp[5][c], tp[7][c], tnw_w, tne_w, tsw_w, tse_w);
         }
         // next pair: the next live view of this sample, else the first live view of the next one
-        if (live) fetch_taps(tab, __builtin_ctz(live));
-        else if (live_n) fetch_taps(tab_next, __builtin_ctz(live_n));
+        if (SEM_PREFETCH) {
+          if (live) fetch_taps(tab, __builtin_ctz(live));
+          else if (live_n) fetch_taps(tab_next, __builtin_ctz(live_n));
+        }
       }
       float w3 = w3u, w2 = w2u;
       if (vis != 0) {
@@ -1424,8 +1439,9 @@ k_sem(gpn_sem_args_t a) {
 #pragma unroll
           for (int k = 0; k < 8; k += 2) {
             const f4 h = ld4(hp + (p * 8 + k) * 2);  // (k, 2p) (k, 2p+1) (k+1, 2p) (k+1, 2p+1)
-            lg = a2w[p][k] * h.lo + lg;
-            lg = a2w[p][k + 1] * h.hi + lg;
+            const f4 w = ld4(sW + ((p * 4 + (k >> 1)) * 64 + lane) * 4);
+            lg = w.lo * h.lo + lg;
+            lg = w.hi * h.hi + lg;
           }
           f2 at;
           at.x = __builtin_amdgcn_exp2f(lg.x);

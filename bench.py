@@ -164,7 +164,12 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="print a per-stage time table to stderr")
     ap.add_argument("--precision", default="bf16x3", choices=("fp32", "bf16x3"),
                     help="arithmetic of the GNT linear layers (see include/gpnerf_hip.h)")
+    ap.add_argument("--only-timed", action="store_true",
+                    help="skip the other arithmetic mode, the full-image run and the CPU baseline "
+                         "(tools/profile_round.sh: the profiled kernels are then the timed workload only)")
     a = ap.parse_args()
+    if a.only_timed:
+        a.cpu_rays = 0
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -265,7 +270,8 @@ def main():
                         "flops_per_launch": flops_per_launch,
                         "executed_mfma_TFLOPs": ex_flops / (mean_ms * 1e-3) / 1e12}
 
-    if True:  # the other arithmetic mode on the same workload (shorter run; every rank takes part)
+    other = None
+    if not a.only_timed:  # the other arithmetic mode on the same workload (shorter run; every rank takes part)
         omode = "fp32" if a.precision == "bf16x3" else "bf16x3"
         _, dt_o, _ = timed(omode, max(3, a.steps // 2), 2)
         other = {"precision": omode, "value": world * CHUNK * max(3, a.steps // 2) / dt_o,
@@ -284,7 +290,7 @@ def main():
     # secondary metric: seconds per full image through render_single_image, results
     # on the host (BASELINE configs[1]: Replica 640x480, render_stride 2 as in gpnerf_replica.txt)
     full_image = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not a.only_timed:
         from gp_nerf_amd.render_image import render_single_image
         stride = 2
         idx = (torch.arange(0, scene.H, stride)[:, None] * scene.W +

@@ -63,7 +63,7 @@ class ProjectArgs(C.Structure):
                 ("deep", C.c_void_p), ("deep_h", C.c_int), ("deep_w", C.c_int), ("deep_c", C.c_int),
                 ("rgb_feat", C.c_void_p), ("deep_out", C.c_void_p), ("ray_diff", C.c_void_p),
                 ("mask", C.c_void_p), ("pix", C.c_void_p), ("taps", C.c_void_p),
-                ("front", C.c_void_p)]
+                ("front", C.c_void_p), ("rgb_feat_ld", C.c_int)]
 
 
 class SemArgs(C.Structure):
@@ -94,7 +94,7 @@ _SIGS = {
     "gpn_project_gather": (C.c_int, [C.POINTER(ProjectArgs), _P]),
     "gpn_posenc": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "gpn_rgbfeat": (C.c_int, [C.POINTER(Linear), C.POINTER(Linear), _P, C.c_int, C.c_int, C.c_int,
-                              _P, _P, _P]),
+                              C.c_int, _P, _P, _P, _P]),
     "gpn_view_attn": (C.c_int, [C.POINTER(ViewLayer), _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P,
                                 C.c_int, _P, C.c_int, _P]),
     "gpn_view_fold": (C.c_int, [C.POINTER(ViewLayer), _P, _P]),
@@ -107,7 +107,7 @@ _SIGS = {
     "gpn_heads": (C.c_int, [C.POINTER(GntWeights), _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P,
                             _P]),
     "gpn_gnt_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
-    "gpn_gnt_forward": (C.c_int, [C.POINTER(GntWeights), _P, _P, _P, _P, _P, _P, C.c_int, C.c_int,
+    "gpn_gnt_forward": (C.c_int, [C.POINTER(GntWeights), _P, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int,
                                   C.c_int, C.POINTER(SemArgs), _P, _P, _P, _P, C.c_size_t, _P]),
     "gpn_set_precision": (C.c_int, [C.c_int]),
     "gpn_get_precision": (C.c_int, []),

@@ -101,7 +101,8 @@ __global__ void k_posenc(const float* __restrict__ pts, const float* __restrict_
 template <bool SPL>
 __global__ void __launch_bounds__(RF_TPB)
 k_rgbfeat(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ rgb_feat, long long N, int V,
-          int in_ch, float* __restrict__ feat, float* __restrict__ q0) {
+          int in_ch, int in_ld, const float* __restrict__ mask, float* __restrict__ feat,
+          float* __restrict__ q0) {
   float* W0 = smem;
   float* W2 = W0 + wimg_floats(SPL, 64, 3, RF_LD0);
   float* b0 = W2 + wimg_floats(SPL, 64, 4, LDW);
@@ -115,29 +116,58 @@ k_rgbfeat(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ rgb_feat
   const int j = lane & 15, g = lane >> 4;
   const long long ntiles = (N + 15) >> 4;
   const long long tstride = (long long)gridDim.x * (RF_TPB / 64);
-  // input row of (point, view), zero-padded to 48 channels; rows are 35 floats (not 16-byte aligned)
+  // input row of (point, view), zero-padded to 48 channels.  Rows are in_ld floats apart: the
+  // reference's dense layout (35) is read element-wise (rows are not 16-byte aligned: 12 requests per
+  // lane); rows padded to a multiple of 4 floats (the fused path: 36) are read as 16-byte units
+  const bool vec = (in_ld & 3) == 0;  // (base alignment checked on the host)
   auto load_row = [&](long long n_, int v_, f4* x_) {
-    const float* row = rgb_feat + ((size_t)n_ * V + v_) * in_ch;
+    const float* row = rgb_feat + ((size_t)n_ * V + v_) * in_ld;
+    if (vec) {
 #pragma unroll
-    for (int T = 0; T < 3; ++T)
+      for (int T = 0; T < 3; ++T) {
+        const int c = 16 * T + 4 * g;
+        x_[T] = c < in_ld ? ld4(row + c) : f4_zero();
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = 16 * T + 4 * g + r;
-        x_[T][r] = c < in_ch ? row[c] : 0.0f;
+        for (int r = 0; r < 4; ++r) x_[T][r] = c + r < in_ch ? x_[T][r] : 0.0f;
       }
+    } else {
+#pragma unroll
+      for (int T = 0; T < 3; ++T)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * T + 4 * g + r;
+          x_[T][r] = c < in_ch ? row[c] : 0.0f;
+        }
+    }
+  };
+  // mask given: the feature row of a masked pair is not stored unless its point has no visible view
+  // at all (gpn_view_attn reads the rows of visible pairs, and every row of such a point)
+  auto vis_of = [&](long long n_) {
+    unsigned b = 0;
+    if (mask != nullptr) {
+      for (int v_ = 0; v_ < V; ++v_) b |= (mask[(size_t)n_ * V + v_] != 0.0f ? 1u : 0u) << (v_ & 31);
+      if (b == 0) b = 0xffffffffu;
+    } else {
+      b = 0xffffffffu;
+    }
+    return b;
   };
   long long tile = (long long)blockIdx.x * (RF_TPB / 64) + wave;
   if (tile >= ntiles) return;
   f4 xpre[3];  // the next (tile, view) row is loaded one iteration ahead
+  unsigned wr_next;
   {
     const long long n0 = tile * 16 + j;
     load_row(n0 < N ? n0 : N - 1, 0, xpre);
+    wr_next = vis_of(n0 < N ? n0 : N - 1);
   }
   for (; tile < ntiles; tile += tstride) {
     const long long n = tile * 16 + j;
     const bool valid = n < N;
     const long long nc = valid ? n : N - 1;
     const long long nn = (tile + tstride) * 16 + j, nnc = nn < N ? nn : N - 1;
+    const unsigned wr = valid ? wr_next : 0u;  // views whose rows this lane's point stores
+    if (tile + tstride < ntiles) wr_next = vis_of(nnc);
     f4 qmax[4];
 #pragma unroll
     for (int M = 0; M < 4; ++M) qmax[M] = f4_splat(-INFINITY);
@@ -160,12 +190,12 @@ k_rgbfeat(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ rgb_feat
       if constexpr (SPL) {
         // split encoding of a feature row (gnt_mfma.h: feat_row_*): the operand split is done once
         // here instead of once per transformer layer in k_view_attn
-        if (valid) store_feat_split(feat + ((size_t)nc * V + v) * C64, y, g);
+        if ((wr >> (v & 31)) & 1u) store_feat_split(feat + ((size_t)nc * V + v) * C64, y, g);
       } else {
         float* out = feat + ((size_t)nc * V + v) * C64 + 4 * g;
 #pragma unroll
         for (int M = 0; M < 4; ++M)
-          if (valid) st4(out + 16 * M, y[M]);
+          if ((wr >> (v & 31)) & 1u) st4(out + 16 * M, y[M]);
       }
 #pragma unroll
       for (int M = 0; M < 4; ++M) qmax[M] = f4_max(qmax[M], y[M]);
@@ -679,6 +709,12 @@ const bool vis_v = MODE == VM_HOMOG || ((vis >> v) & 1u) != 0;
           if (!vis_v) {
 #pragma unroll
             for (int M = 0; M < 4; ++M) a[M] = f4_splat(-1e9f);  // masked_fill (:83)
+            // its weight is exactly 0 once the point has a visible view; the feature row of such a
+            // pair may never have been stored (gpn_rgbfeat with a mask): keep 0 * garbage out of the sum
+            if (vis != 0) {
+#pragma unroll
+              for (int M = 0; M < 4; ++M) vp[M] = f4_zero();
+            }
           }
         }
         if constexpr (MODE == VM_HOMOG) {
@@ -1570,7 +1606,8 @@ extern "C" int gpn_posenc(const float* pts, const float* ray_d, int R, int S, fl
 }
 
 extern "C" int gpn_rgbfeat(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* rgb_feat,
-                           int N, int V, int in_ch, float* feat, float* q0, gpn_stream_t stream) {
+                           int N, int V, int in_ch, int in_ld, const float* mask, float* feat,
+                           float* q0, gpn_stream_t stream) {
   if (N == 0) return GPN_OK;  // empty batch (pointers may be null)
   GPN_REQUIRE(fc0 && fc2 && rgb_feat && feat && q0, "gpn_rgbfeat: null pointer");
   REQ_LIN(*fc2, "gpn_rgbfeat.fc2");
@@ -1578,17 +1615,20 @@ extern "C" int gpn_rgbfeat(const gpn_linear_t* fc0, const gpn_linear_t* fc2, con
   GPN_REQUIRE(N >= 0 && V >= 1 && V <= GPN_MAX_VIEWS && in_ch >= 1 && in_ch <= 48,
               "gpn_rgbfeat: need 1<=V<=%d, in_ch<=48 (got V=%d in_ch=%d)", GPN_MAX_VIEWS, V, in_ch);
   GPN_REQUIRE(aligned16(feat) && aligned16(q0), "gpn_rgbfeat: outputs must be 16-byte aligned");
-  if (N == 0) return GPN_OK;
+  if (in_ld == 0) in_ld = in_ch;
+  GPN_REQUIRE(in_ld >= in_ch && in_ld <= 48, "gpn_rgbfeat: in_ld must be 0 or in [in_ch,48] (got %d)", in_ld);
+  GPN_REQUIRE((in_ld & 3) != 0 || aligned16(rgb_feat),
+              "gpn_rgbfeat: rgb_feat with rows of a multiple of 4 floats must be 16-byte aligned");
   const bool spl = gpn_precision() == GPN_PREC_BF16X3;
   const size_t lds = sizeof(float) * (wimg_floats(spl, 64, 3, RF_LD0) + wimg_floats(spl, 64, 4, LDW) + 128);
   const int grid = persistent_grid(((long long)N + (RF_TPB / 4) - 1) / (RF_TPB / 4));
   GpnStageTimer timer_k_rgbfeat_(GPN_ST_RGBFEAT, (hipStream_t)stream);
   if (spl)
     hipLaunchKernelGGL(k_rgbfeat<true>, dim3(grid), dim3(RF_TPB), lds, (hipStream_t)stream, *fc0, *fc2,
-                       rgb_feat, (long long)N, V, in_ch, feat, q0);
+                       rgb_feat, (long long)N, V, in_ch, in_ld, mask, feat, q0);
   else
     hipLaunchKernelGGL(k_rgbfeat<false>, dim3(grid), dim3(RF_TPB), lds, (hipStream_t)stream, *fc0, *fc2,
-                       rgb_feat, (long long)N, V, in_ch, feat, q0);
+                       rgb_feat, (long long)N, V, in_ch, in_ld, mask, feat, q0);
   GPN_LAUNCH_CHECK("k_rgbfeat");
   return GPN_OK;
 }
@@ -1865,7 +1905,7 @@ extern "C" size_t gpn_gnt_workspace_bytes(int R, int S, int V, int depth) {
   return gnt_ws_layout(R, S, V, depth).total;
 }
 
-extern "C" int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat,
+extern "C" int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat, int rgb_feat_ld,
                                const float* ray_diff, const float* mask, const float* pts,
                                const float* ray_d, const float* z_vals, int R, int S, int V,
                                gpn_sem_args_t* sem, float* out, float* depth, float* sem_feat,
@@ -1895,8 +1935,9 @@ extern "C" int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat
   int rc;
   if ((rc = gpn_vis_order(mask, (int)N, V, perm, ws + L.vis_scratch, stream))) return rc;
   if ((rc = gpn_posenc(pts, ray_d, R, S, emb, stream))) return rc;
-  if ((rc = gpn_rgbfeat(&W->rgbfeat0, &W->rgbfeat2, rgb_feat, (int)N, V, 3 + W->in_feat_ch, feat, q,
-                        stream)))
+  // (mask given: the feature rows of masked pairs, which gpn_view_attn never uses, are not stored)
+  if ((rc = gpn_rgbfeat(&W->rgbfeat0, &W->rgbfeat2, rgb_feat, (int)N, V, 3 + W->in_feat_ch, rgb_feat_ld,
+                        mask, feat, q, stream)))
     return rc;
   for (int l = 0; l < D; ++l) {
     // side outputs for the semantic aggregation, interleaved over the layers

@@ -44,7 +44,9 @@ k_project_feat(gpn_project_args_t a, long long n_pairs) {
   for (int i = tid; i < a.V * 3; i += 256) sPos[i] = a.src_pos[i];
   __syncthreads();
   const int slot = tid >> 3, q = tid & 7;
-  const int OC = 3 + a.feat_c;  // 35
+  // 35 channels; rows of the output are LD floats apart (36 on the fused path: 16-byte aligned rows,
+  // channels OC.. are written as zeros)
+  const int OC = 3 + a.feat_c, LD = a.rgb_feat_ld > 0 ? a.rgb_feat_ld : OC;
   const bool gather = a.rgb_feat != nullptr;  // false: geometry only (pix / mask / ray_diff)
 
   for (long long base = (long long)blockIdx.x * PAIRS; base < n_pairs;
@@ -67,7 +69,7 @@ k_project_feat(gpn_project_args_t a, long long n_pairs) {
         if (t.vy0 && t.vx1) vne = *reinterpret_cast<const float4*>(fm + o00 + a.feat_c);
         if (t.vy1 && t.vx0) vsw = *reinterpret_cast<const float4*>(fm + o00 + rs);
         if (t.vy1 && t.vx1) vse = *reinterpret_cast<const float4*>(fm + o00 + rs + a.feat_c);
-        float* o = sOut + slot * OC + 3 + q * 4;
+        float* o = sOut + slot * LD + 3 + q * 4;
         o[0] = gpn_bilerp(vnw.x, vne.x, vsw.x, vse.x, t);
         o[1] = gpn_bilerp(vnw.y, vne.y, vsw.y, vse.y, t);
         o[2] = gpn_bilerp(vnw.z, vne.z, vsw.z, vse.z, t);
@@ -83,12 +85,14 @@ k_project_feat(gpn_project_args_t a, long long n_pairs) {
         if (gather && t.vy0 && t.vx1) vne = im[o00 + 3];
         if (gather && t.vy1 && t.vx0) vsw = im[o00 + rs];
         if (gather && t.vy1 && t.vx1) vse = im[o00 + rs + 3];
-        if (gather) sOut[slot * OC + q] = gpn_bilerp(vnw, vne, vsw, vse, t);
+        if (gather) sOut[slot * LD + q] = gpn_bilerp(vnw, vne, vsw, vse, t);
         if (q == 0 && a.taps) {
           a.taps[((size_t)v * a.N + n) * 2 + 0] = t.x0;
           a.taps[((size_t)v * a.N + n) * 2 + 1] = t.y0;
         }
       } else if (q == 3) {  // mask (projection.py:133-138)
+        if (gather)
+          for (int c = OC; c < LD; ++c) sOut[slot * LD + c] = 0.0f;
         const bool m = pp.front && gpn_inbound(pp.px, pp.py, a.img_h, a.img_w);
         if (a.mask) a.mask[pair] = m ? 1.0f : 0.0f;
         if (a.front) a.front[(size_t)v * a.N + n] = pp.front ? 1 : 0;
@@ -114,9 +118,9 @@ k_project_feat(gpn_project_args_t a, long long n_pairs) {
     __syncthreads();
     // coalesced copy-out of this block's contiguous [pairs, OC] span
     const long long left = n_pairs - base;
-    const int cnt = (int)(left < PAIRS ? left : PAIRS) * OC;
-    float* dst = a.rgb_feat + base * OC;
-    if (((base * OC) & 3) == 0) {
+    const int cnt = (int)(left < PAIRS ? left : PAIRS) * LD;
+    float* dst = a.rgb_feat + base * LD;
+    if (((base * LD) & 3) == 0) {
       for (int i = tid * 4; i + 3 < cnt; i += 256 * 4)
         *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(sOut + i);
       for (int i = (cnt & ~3) + tid; i < cnt; i += 256) dst[i] = sOut[i];
@@ -192,6 +196,9 @@ extern "C" int gpn_project_gather(const gpn_project_args_t* a, gpn_stream_t stre
     GPN_REQUIRE(a->feat_c == 32, "gpn_project_gather: feature maps must have 32 channels (got %d)",
                 a->feat_c);
     GPN_REQUIRE(a->feat_h >= 1 && a->feat_w >= 1, "gpn_project_gather: bad feature map size");
+    GPN_REQUIRE(a->rgb_feat_ld == 0 || (a->rgb_feat_ld >= 3 + a->feat_c && a->rgb_feat_ld <= 36),
+                "gpn_project_gather: rgb_feat_ld must be 0 or in [%d,36] (got %d)", 3 + a->feat_c,
+                a->rgb_feat_ld);
   }
   GPN_REQUIRE(a->img_h > 1.0f && a->img_w > 1.0f, "gpn_project_gather: bad image size");
   const bool want_deep = a->deep_out != nullptr;

@@ -116,7 +116,7 @@ class Projector:
                 raise ValueError("deep_semantics must have one map per source view")
         return sv
 
-    def _launch(self, xyz, sv, want_feat, want_deep, want_geom=True, want_pix=False):
+    def _launch(self, xyz, sv, want_feat, want_deep, want_geom=True, want_pix=False, feat_ld=0):
         pts = _lib.dev_f32(_lib.as_f32c(xyz), "xyz").reshape(-1, 3)
         lead = tuple(xyz.shape[:-1])
         N, V, dev = pts.shape[0], sv.V, pts.device
@@ -129,8 +129,8 @@ class Projector:
         if want_feat:
             a.feat = _lib.ptr(sv.feat)
             a.feat_h, a.feat_w, a.feat_c = sv.feat.shape[1:]
-            out["rgb_feat"] = torch.empty(lead + (V, 3 + sv.feat.shape[3]), device=dev)
-            a.rgb_feat = _lib.ptr(out["rgb_feat"])
+            out["rgb_feat"] = torch.empty(lead + (V, feat_ld or 3 + sv.feat.shape[3]), device=dev)
+            a.rgb_feat, a.rgb_feat_ld = _lib.ptr(out["rgb_feat"]), feat_ld
         if want_deep:
             a.deep = _lib.ptr(sv.deep)
             a.deep_h, a.deep_w, a.deep_c = sv.deep.shape[1:]
@@ -179,6 +179,8 @@ class Projector:
 
     def compute_fused(self, xyz, sv):
         """Fast path used by render_rays: no [R,S,V,512] materialisation (the deep-semantic maps are
-        sampled later, inside gpn_sem_aggregate)."""
-        out = self._launch(xyz, sv, True, False)
+        sampled later, inside gpn_sem_aggregate).  rgb_feat comes back with rows padded to 36 floats
+        (16-byte aligned rows, channels 35.. zero): the layout gpn_rgbfeat reads as whole 16-byte units;
+        GNT.run takes either width."""
+        out = self._launch(xyz, sv, True, False, feat_ld=36 if sv.feat.shape[3] == 32 else 0)
         return out["rgb_feat"], out["ray_diff"], out["mask"]

@@ -189,8 +189,11 @@ class GNT(nn.Module):
         Returns out [R,3+S], depth [R] or None, sem_feat [R,512] or None, sem_feat_3d or None."""
         rgb_feat = _lib.dev_f32(_lib.as_f32c(rgb_feat), "rgb_feat")
         R, S, V = rgb_feat.shape[:3]
-        if rgb_feat.shape[3] != 3 + self.in_feat_ch:
-            raise ValueError("rgb_feat must have %d channels" % (3 + self.in_feat_ch))
+        # 3+F channels (reference layout) or rows padded to 36 floats (Projector.compute_fused)
+        in_ch = 3 + self.in_feat_ch
+        ld = rgb_feat.shape[3]
+        if ld != in_ch and not (ld == 36 and in_ch <= 36):
+            raise ValueError("rgb_feat must have %d channels" % in_ch)
         dev = rgb_feat.device
         ray_diff = _lib.dev_f32(_lib.as_f32c(ray_diff), "ray_diff", (R, S, V, 4))
         mask = _lib.dev_f32(_lib.as_f32c(mask), "mask").reshape(R, S, V)
@@ -225,7 +228,7 @@ class GNT(nn.Module):
                 sem.xyz, sem.proj = _lib.ptr(pts), _lib.ptr(deep_map["proj"])
                 sem.img_h, sem.img_w = deep_map["img_h"], deep_map["img_w"]
         _lib.check(_lib.lib().gpn_gnt_forward(
-            C.byref(W), _lib.ptr(rgb_feat), _lib.ptr(ray_diff), _lib.ptr(mask), _lib.ptr(pts),
+            C.byref(W), _lib.ptr(rgb_feat), ld, _lib.ptr(ray_diff), _lib.ptr(mask), _lib.ptr(pts),
             _lib.ptr(ray_d), _lib.ptr(z_vals), R, S, V, C.byref(sem) if sem is not None else None,
             _lib.ptr(out), _lib.ptr(depth), _lib.ptr(sem_feat), _lib.ptr(ws), need, _lib.stream()),
             "gpn_gnt_forward")

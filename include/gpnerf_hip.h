@@ -115,6 +115,9 @@ typedef struct {
   float* pix;            /* out [V,N,2] clamped pixel coordinates, or NULL */
   int32_t* taps;         /* out [V,N,2] floor() of the RGB-map sampling coordinate (x0,y0), or NULL */
   uint8_t* front;        /* out [V,N] 1 if the point is in front of the camera, or NULL */
+  int rgb_feat_ld;       /* floats between consecutive rgb_feat rows; 0 = 3+F (the reference's dense
+                            layout).  36 gives 16-byte aligned rows (pad written as zeros): what
+                            gpn_rgbfeat reads fastest; used by the fused path only */
 } gpn_project_args_t;
 
 /* Projector.compute = compute_projections + inbound + normalize + 3x grid_sample + compute_angle,
@@ -170,9 +173,15 @@ int gpn_posenc(const float* pts, const float* ray_d, int R, int S, float* emb, g
  * GPN_PREC_BF16X3 mode every row of C = 64 channels is stored in the operand format of that mode (same
  * 256 bytes): 16 units of 8 bf16, unit ((P*2 + hm)*4 + g), P < 2, g < 4, holding the high (hm = 0)
  * or the residual (hm = 1) bf16 piece of channels {32P+4g+r, 32P+16+4g+r : r < 4}; value = hi + mid.
- * Both calls must run in the same mode. */
+ * Both calls must run in the same mode.
+ * in_ld: floats between consecutive rgb_feat rows (0 = in_ch, the reference's dense layout; a
+ * multiple of 4 -- gpn_project_args_t.rgb_feat_ld = 36 -- needs a 16-byte aligned rgb_feat and is read
+ * as 16-byte units).  mask [N,V] or NULL: with a mask the feature row of a masked pair is not stored
+ * (its attention weight is exactly 0) unless the point has no visible view at all; q0 is the maximum
+ * over ALL views either way, as in the reference. */
 int gpn_rgbfeat(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* rgb_feat, int N,
-                int V, int in_ch, float* feat, float* q0, gpn_stream_t stream);
+                int V, int in_ch, int in_ld, const float* mask, float* feat, float* q0,
+                gpn_stream_t stream);
 
 /* Attention part of Transformer2D (attn_norm, Attention2D, residual), transformer_network.py:74-88
  * and :107-112.  q_in [N,C], feat [N,V,C], ray_diff [N,V,4], mask [N,V] -> q_out [N,C];
@@ -263,10 +272,11 @@ int gpn_heads(const gpn_gnt_weights_t* W, const float* q, const float* weights, 
               gpn_stream_t stream);
 
 /* Whole GNT.forward (transformer_network.py:295-338) on a caller-provided workspace.
- * Inputs as gpn_rgbfeat / gpn_view_attn; `sem` carries the deep-semantic source and outputs
+ * Inputs as gpn_rgbfeat / gpn_view_attn (rgb_feat_ld = its in_ld); `sem` carries the deep-semantic source and outputs
  * (its hidden/stats/abar/mask/R/S/V/depth/attn2_* fields are filled in by this call); sem may be NULL. */
 size_t gpn_gnt_workspace_bytes(int R, int S, int V, int depth);
-int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat, const float* ray_diff,
+int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat, int rgb_feat_ld,
+                    const float* ray_diff,
                     const float* mask, const float* pts, const float* ray_d, const float* z_vals,
                     int R, int S, int V, gpn_sem_args_t* sem, float* out, float* depth,
                     float* sem_feat, void* workspace, size_t workspace_bytes, gpn_stream_t stream);

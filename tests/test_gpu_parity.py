@@ -145,7 +145,9 @@ def test_projector_taps_and_helpers(dev):
     # fused path == full path on the shared outputs
     a = P.compute_fused(cd["pts"], sv)
     b = P.compute(cd["pts"], cd["camera"], cd["src_rgbs"], cd["src_cameras"], cd["featmaps"], None)
-    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[3]) and b[1] is None
+    # (the fused path pads its rows to 36 floats: channels 35.. are zero)
+    assert torch.equal(a[0][..., :35], b[0]) and bool((a[0][..., 35:] == 0).all())
+    assert torch.equal(a[2], b[3]) and b[1] is None
 
 
 def test_projector_ragged_and_empty(dev):
@@ -302,10 +304,23 @@ def test_gnt_stages(dev, net, prec, S):
     # rgbfeat
     feat, q0 = e(N, V, 64), e(N, 64)
     _lib.check(L.gpn_rgbfeat(C.byref(W.rgbfeat0), C.byref(W.rgbfeat2), _lib.ptr(rgbf_d), N, V,
-                             35, _lib.ptr(feat), _lib.ptr(q0), st), "rgbfeat")
+                             35, 0, None, _lib.ptr(feat), _lib.ptr(q0), st), "rgbfeat")
     errs["feat"] = rel(dec_feat(feat, prec), rec["feat"].reshape(N, V, 64))
     errs["q0"] = rel(q0, rec["q0"].reshape(N, 64))
     rd, mk = f(c["ray_diff"]), f(c["mask"])
+    # the fused path's form of the same call: rows padded to 36 floats (garbage in the pad), feature
+    # rows of masked pairs not stored (unless the point has no visible view): same bits elsewhere
+    rgbf36 = torch.full((N, V, 36), float("nan"), device=dev)
+    rgbf36[..., :35] = rgbf_d.reshape(N, V, 35)
+    feat_m, q0_m = torch.full((N, V, 64), float("nan"), device=dev), e(N, 64)
+    _lib.check(L.gpn_rgbfeat(C.byref(W.rgbfeat0), C.byref(W.rgbfeat2), _lib.ptr(rgbf36), N, V,
+                             35, 36, _lib.ptr(mk), _lib.ptr(feat_m), _lib.ptr(q0_m), st), "rgbfeat-masked")
+    vis_nv = mk.reshape(N, V) != 0
+    stored = vis_nv | ~vis_nv.any(dim=1, keepdim=True)
+    assert torch.equal(q0_m, q0), "padded rows / masked stores changed q0"
+    assert torch.equal(feat_m[stored].view(torch.int32), feat[stored].view(torch.int32)), \
+        "padded rows / masked stores changed a stored feature row"
+    assert bool(torch.isnan(feat_m[~stored]).all()), "the feature row of a masked pair was stored"
     feat_ref = f(enc_feat(rec["feat"].reshape(N, V, 64), prec))
     emb_ref = f(want)
     for l in (0, 1, 7):
@@ -324,6 +339,14 @@ def test_gnt_stages(dev, net, prec, S):
                                        _lib.ptr(mk), None, N, V, _lib.ptr(qo_p), None, 64, None, 64, st),
                        "view-unfolded")
             errs["view_attn_unfolded"] = rel(qo_p, rec["q_view_attn"][l].reshape(N, 64))
+        if l == 0:  # rows gpn_rgbfeat leaves unstored (NaN here) must not reach the result
+            feat_nan = feat_ref.clone()
+            feat_nan[~stored] = float("nan")
+            qo_n = e(N, 64)
+            _lib.check(L.gpn_view_attn(C.byref(W.view[l]), _lib.ptr(q_in), _lib.ptr(feat_nan), _lib.ptr(rd),
+                                       _lib.ptr(mk), None, N, V, _lib.ptr(qo_n), None, 8, None, 64, st),
+                       "view-unstored-rows")
+            assert torch.equal(qo_n, qo), "an unstored feature row changed the view attention"
         # same launch in visibility-sorted order: bit-identical outputs
         perm2 = torch.empty(2 * N, dtype=torch.int32, device=dev)
         scr = torch.empty(L.gpn_vis_order_scratch_bytes(), dtype=torch.uint8, device=dev)
@@ -444,10 +467,26 @@ def test_gnt_stages_many_tiles(dev, net, prec):
     want = oracle.gnt._lin(sd, "rgbfeat_fc.2", F.relu(oracle.gnt._lin(sd, "rgbfeat_fc.0", rgbf)))
     fo, q0 = e(N, V, 64), e(N, 64)
     rgbf_d = f(rgbf.reshape(N, V, 35))
-    _lib.check(L.gpn_rgbfeat(C.byref(W.rgbfeat0), C.byref(W.rgbfeat2), _lib.ptr(rgbf_d), N, V, 35,
-                             _lib.ptr(fo), _lib.ptr(q0), st), "rgbfeat")
+    _lib.check(L.gpn_rgbfeat(C.byref(W.rgbfeat0), C.byref(W.rgbfeat2), _lib.ptr(rgbf_d), N, V, 35, 0,
+                             None, _lib.ptr(fo), _lib.ptr(q0), st), "rgbfeat")
     errs["feat"] = rel(dec_feat(fo, prec), want.reshape(N, V, 64))
     errs["q0"] = rel(q0, want.max(dim=2)[0].reshape(N, 64))
+    # padded rows + masked stores over many tiles per wave: same bits wherever a row is stored
+    rgbf36 = torch.full((N, V, 36), float("nan"), device=dev)
+    rgbf36[..., :35] = rgbf_d
+    fo_m, q0_m = torch.full((N, V, 64), float("nan"), device=dev), e(N, 64)
+    _lib.check(L.gpn_rgbfeat(C.byref(W.rgbfeat0), C.byref(W.rgbfeat2), _lib.ptr(rgbf36), N, V, 35, 36,
+                             _lib.ptr(mk), _lib.ptr(fo_m), _lib.ptr(q0_m), st), "rgbfeat-masked")
+    vis_nv = mk != 0
+    stored = vis_nv | ~vis_nv.any(dim=1, keepdim=True)
+    assert torch.equal(q0_m, q0) and torch.equal(fo_m[stored].view(torch.int32), fo[stored].view(torch.int32))
+    assert bool(torch.isnan(fo_m[~stored]).all())
+    fd_nan = fd.clone()
+    fd_nan[~stored] = float("nan")
+    qo_n = e(N, 64)
+    _lib.check(L.gpn_view_attn(C.byref(W.view[0]), _lib.ptr(qd), _lib.ptr(fd_nan), _lib.ptr(rd), _lib.ptr(mk),
+                               _lib.ptr(perm2), N, V, _lib.ptr(qo_n), None, 8, None, 64, st), "view-unstored")
+    assert torch.equal(qo_n, qo), "an unstored feature row changed the view attention"
     # q positional MLP (layer 0)
     xin = torch.cat([q.reshape(N, 64), emb[:, :126]], -1)
     want = oracle.gnt._lin(sd, "q_fcs.0.2", F.relu(oracle.gnt._lin(sd, "q_fcs.0.0", xin)))

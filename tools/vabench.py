@@ -31,8 +31,8 @@ ray_diff = ray_diff.reshape(N, V, 4).contiguous()
 feat = torch.empty(N, V, 64, device=dev)
 q = torch.empty(N, 64, device=dev)
 rgb_feat = rgb_feat.reshape(N, V, -1).contiguous()
-_lib.check(L.gpn_rgbfeat(C.byref(W.rgbfeat0), C.byref(W.rgbfeat2), _lib.ptr(rgb_feat), N, V, rgb_feat.shape[-1],
-                         _lib.ptr(feat), _lib.ptr(q), st), "rgbfeat")
+_lib.check(L.gpn_rgbfeat(C.byref(W.rgbfeat0), C.byref(W.rgbfeat2), _lib.ptr(rgb_feat), N, V, 35, rgb_feat.shape[-1],
+                         None, _lib.ptr(feat), _lib.ptr(q), st), "rgbfeat")
 qo = torch.empty_like(q)
 logits = torch.empty(N, V, 8, 8, device=dev)  # hidden side channel [N,V,depth,8]
 stats = torch.empty(N, 8, 64, device=dev)

@@ -47,6 +47,18 @@
 
 extern __shared__ __attribute__((aligned(16))) float smem[];
 
+// Development aid (tools/kbench.py, -DGPN_STAMP builds only): wall-clock stamps (10 ns units) taken by
+// thread 0 of workgroup 0 at marked places of a kernel, read back with gpn_debug_stamps.
+#ifdef GPN_STAMP
+__device__ unsigned long long g_stamps[64];
+#define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[i] = wall_clock64(); } while (0)
+extern "C" int gpn_debug_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : 1;
+}
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 
 
 static int set_lds_limit(const void* fn, size_t bytes) {
@@ -108,10 +120,15 @@ k_rgbfeat(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ rgb_feat
   float* b0 = W2 + wimg_floats(SPL, 64, 4, LDW);
   float* b2 = b0 + 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  stage_w<SPL>(W0, RF_LD0, fc0.w, 64, in_ch, 64, 3, tid, RF_TPB);
-  stage_w<SPL>(W2, LDW, fc2.w, 64, 64, 64, 4, tid, RF_TPB);
-  stage_vector(b0, 64, fc0.b, 64, tid, RF_TPB);
-  stage_vector(b2, 64, fc2.b, 64, tid, RF_TPB);
+  {  // two-phase staging (gnt_mfma.h): every global load first, then the LDS images
+    WStage<SPL, 64, 3, RF_TPB> s0;
+    WStage<SPL, 64, 4, RF_TPB> s2;
+    VecStage<64, RF_TPB> v0, v2;
+    s0.load(fc0.w, 64, in_ch, tid), s2.load(fc2.w, 64, 64, tid);
+    v0.load(fc0.b, 64, tid), v2.load(fc2.b, 64, tid);
+    s0.store(W0, RF_LD0, tid), s2.store(W2, LDW, tid);
+    v0.store(b0, tid), v2.store(b2, tid);
+  }
   __syncthreads();
   const int j = lane & 15, g = lane >> 4;
   const long long ntiles = (N + 15) >> 4;
@@ -383,30 +400,54 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
   const ViewLds L = view_lds<SPL>(smem);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (tile loop, LDS-DMA base)
-  stage_w<SPL>(L.Wq, LDW, Lw.q.w, 64, 64, 64, 4, tid, VA_TPB);
+  STAMP(0);
   static_assert(SPL || !FOLD, "the folded algorithm exists in split mode only");
-  if constexpr (FOLD) {  // Wv slot holds Wv Wk; k itself is never formed
-    stage_w<SPL>(L.Wv, LDW, Lw.folded + FOLD_VK, 64, 64, 64, 4, tid, VA_TPB);
-    stage_w<SPL>(L.AF, 0, Lw.folded + FOLD_AF, 16, 96, 16, 6, tid, VA_TPB);
-    stage_vector(L.c0, 16, Lw.folded + FOLD_C0, 16, tid, VA_TPB);
-  } else {
-    stage_w<SPL>(L.Wk, LDW, Lw.k.w, 64, 64, 64, 4, tid, VA_TPB);
-    stage_w<SPL>(L.Wv, LDW, Lw.v.w, 64, 64, 64, 4, tid, VA_TPB);
+  {  // two-phase staging (gnt_mfma.h): every global load first, then the LDS images
+    WStage<SPL, 64, 4, VA_TPB> sq, sk, sv, so;
+    WStage<SPL, 16, 6, VA_TPB> saf;
+    WStage<SPL, 64, 1, VA_TPB> sp2, sa2;
+    WStage<SPL, 16, 4, VA_TPB> sa0;
+    RowStage<16, 1, VA_TPB> sp0;
+    VecStage<16, VA_TPB> vc0, vbp0, vba0;
+    VecStage<64, VA_TPB> vbp2, vba2, vbo, vga, vbe;
+    sq.load(Lw.q.w, 64, 64, tid);
+    if constexpr (FOLD) {  // Wv slot holds Wv Wk; k itself is never formed
+      sv.load(Lw.folded + FOLD_VK, 64, 64, tid);
+      saf.load(Lw.folded + FOLD_AF, 16, 96, tid);
+      vc0.load(Lw.folded + FOLD_C0, 16, tid);
+    } else {
+      sk.load(Lw.k.w, 64, 64, tid);
+      sv.load(Lw.v.w, 64, 64, tid);
+    }
+    so.load(Lw.out.w, 64, 64, tid);
+    sp2.load(Lw.pos2.w, 64, 8, tid);
+    sa0.load(Lw.attn0.w, 8, 64, tid);
+    sa2.load(Lw.attn2.w, 64, 8, tid);
+    sp0.load(Lw.pos0.w, 8, 4, tid);
+    vbp0.load(Lw.pos0.b, 8, tid), vbp2.load(Lw.pos2.b, 64, tid), vba0.load(Lw.attn0.b, 8, tid);
+    vba2.load(Lw.attn2.b, 64, tid), vbo.load(Lw.out.b, 64, tid);
+    vga.load(Lw.attn_norm_w, 64, tid), vbe.load(Lw.attn_norm_b, 64, tid);
+    sq.store(L.Wq, LDW, tid);
+    if constexpr (FOLD) {
+      sv.store(L.Wv, LDW, tid);
+      saf.store(L.AF, 0, tid);
+      vc0.store(L.c0, tid);
+    } else {
+      sk.store(L.Wk, LDW, tid);
+      sv.store(L.Wv, LDW, tid);
+    }
+    so.store(L.Wo, LDW, tid);
+    sp2.store(L.P2, VA_LD8, tid);
+    sa0.store(L.A0, LDW, tid);
+    sa2.store(L.A2, VA_LD8, tid);
+    sp0.store(L.P0, 4, tid);
+    vbp0.store(L.bP0, tid), vbp2.store(L.bP2, tid), vba0.store(L.bA0, tid), vba2.store(L.bA2, tid);
+    STAMP(1);
+    vbo.store(L.bO, tid), vga.store(L.gam, tid), vbe.store(L.bet, tid);
   }
-  stage_w<SPL>(L.Wo, LDW, Lw.out.w, 64, 64, 64, 4, tid, VA_TPB);
-  stage_w<SPL>(L.P2, VA_LD8, Lw.pos2.w, 64, 8, 64, 1, tid, VA_TPB);
-  stage_w<SPL>(L.A0, LDW, Lw.attn0.w, 8, 64, 16, 4, tid, VA_TPB);
-  stage_w<SPL>(L.A2, VA_LD8, Lw.attn2.w, 64, 8, 64, 1, tid, VA_TPB);
-  stage_padded(L.P0, 4, 16, 4, Lw.pos0.w, 8, 4, tid, VA_TPB);
-  stage_vector(L.bP0, 16, Lw.pos0.b, 8, tid, VA_TPB);
-  stage_vector(L.bP2, 64, Lw.pos2.b, 64, tid, VA_TPB);
-  stage_vector(L.bA0, 16, Lw.attn0.b, 8, tid, VA_TPB);
-  stage_vector(L.bA2, 64, Lw.attn2.b, 64, tid, VA_TPB);
-  stage_vector(L.bO, 64, Lw.out.b, 64, tid, VA_TPB);
-  stage_vector(L.gam, 64, Lw.attn_norm_w, 64, tid, VA_TPB);
-  stage_vector(L.bet, 64, Lw.attn_norm_b, 64, tid, VA_TPB);
   __syncthreads();
 
+  STAMP(2);
   const int j = lane & 15, g = lane >> 4;
   const float p0w = L.P0[j * 4 + g];  // A operand of the 4 -> 8 layer: W[i = j][k = g]
   const long long ntiles = (N + 15) >> 4;
@@ -615,6 +656,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
     //           exponent range (> ~87 between two views): their sum overflows in the forms above,
     //           which is detected after the loop; the tile is then run a second time in this form
     //           and only those points are stored from it.
+    STAMP(3);
     const unsigned live0 = live;
     const int vfirst = __builtin_ctz(live0);
     // lanes whose results this pass stores (a redo pass: the overflowed points only)
@@ -757,6 +799,7 @@ const bool vis_v = MODE == VM_HOMOG || ((vis >> v) & 1u) != 0;
         }
       }
     };
+    STAMP(4);
     bool store_ok = valid;
     unsigned long long redo_next = 0;
     if (online) {
@@ -826,6 +869,7 @@ const bool vis_v = MODE == VM_HOMOG || ((vis >> v) & 1u) != 0;
     live2 = tile + 2 * tstride < ntiles ? live_of(vis2) : 0u;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last (unused) ring fills land before the wave ends
+  STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------ feed-forward
@@ -846,13 +890,20 @@ k_ff(const float* __restrict__ norm_w, const float* __restrict__ norm_b, gpn_lin
   float* gam = b2 + 64;
   float* bet = gam + 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  stage_w<SPL>(W1, LDW, fc1.w, 256, 64, 256, 4, tid, FF_TPB);
-  stage_w<SPL>(W2, FF_LD2, fc2.w, 64, 256, 64, 16, tid, FF_TPB);
-  stage_vector(b1, 256, fc1.b, 256, tid, FF_TPB);
-  stage_vector(b2, 64, fc2.b, 64, tid, FF_TPB);
-  stage_vector(gam, 64, norm_w, 64, tid, FF_TPB);
-  stage_vector(bet, 64, norm_b, 64, tid, FF_TPB);
+  STAMP(8);
+  {  // two-phase staging (gnt_mfma.h): every global load first, then the LDS images
+    WStage<SPL, 256, 4, FF_TPB> s1;
+    WStage<SPL, 64, 16, FF_TPB> s2;
+    VecStage<256, FF_TPB> v1;
+    VecStage<64, FF_TPB> v2, vg, vb;
+    s1.load(fc1.w, 256, 64, tid), s2.load(fc2.w, 64, 256, tid);
+    v1.load(fc1.b, 256, tid), v2.load(fc2.b, 64, tid), vg.load(norm_w, 64, tid), vb.load(norm_b, 64, tid);
+    s1.store(W1, LDW, tid), s2.store(W2, FF_LD2, tid);
+    STAMP(9);
+    v1.store(b1, tid), v2.store(b2, tid), vg.store(gam, tid), vb.store(bet, tid);
+  }
   __syncthreads();
+  STAMP(10);
   const int j = lane & 15, g = lane >> 4;
   const long long ntiles = (N + 15) >> 4;
   if constexpr (SPL) {
@@ -965,10 +1016,15 @@ k_qpos(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ q_in,
   float* b0 = W2 + wimg_floats(SPL, 64, 4, LDW);
   float* b2 = b0 + 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  stage_w<SPL>(W0, QP_LD0, fc0.w, 64, 190, 64, 12, tid, QP_TPB);
-  stage_w<SPL>(W2, LDW, fc2.w, 64, 64, 64, 4, tid, QP_TPB);
-  stage_vector(b0, 64, fc0.b, 64, tid, QP_TPB);
-  stage_vector(b2, 64, fc2.b, 64, tid, QP_TPB);
+  {  // two-phase staging (gnt_mfma.h): every global load first, then the LDS images
+    WStage<SPL, 64, 12, QP_TPB> s0;
+    WStage<SPL, 64, 4, QP_TPB> s2;
+    VecStage<64, QP_TPB> v0, v2;
+    s0.load(fc0.w, 64, 190, tid), s2.load(fc2.w, 64, 64, tid);
+    v0.load(fc0.b, 64, tid), v2.load(fc2.b, 64, tid);
+    s0.store(W0, QP_LD0, tid), s2.store(W2, LDW, tid);
+    v0.store(b0, tid), v2.store(b2, tid);
+  }
   __syncthreads();
   const int j = lane & 15, g = lane >> 4;
   const long long ntiles = (N + 15) >> 4;
@@ -1043,13 +1099,15 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
   float* Vt = Ks + RPW * SP * LDW;
   float* part = Vt + RPW * 64 * LDV;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  stage_w<SPL>(Wq, LDW, Lw.q.w, 64, 64, 64, 4, tid, NTHR);
-  stage_w<SPL>(Wk, LDW, Lw.k.w, 64, 64, 64, 4, tid, NTHR);
-  stage_w<SPL>(Wv, LDW, Lw.v.w, 64, 64, 64, 4, tid, NTHR);
-  stage_w<SPL>(Wo, LDW, Lw.out.w, 64, 64, 64, 4, tid, NTHR);
-  stage_vector(bO, 64, Lw.out.b, 64, tid, NTHR);
-  stage_vector(gam, 64, Lw.attn_norm_w, 64, tid, NTHR);
-  stage_vector(bet, 64, Lw.attn_norm_b, 64, tid, NTHR);
+  {  // two-phase staging (gnt_mfma.h): every global load first, then the LDS images
+    WStage<SPL, 64, 4, NTHR> sq, sk, sv, so;
+    VecStage<64, NTHR> vo, vg, vb;
+    sq.load(Lw.q.w, 64, 64, tid), sk.load(Lw.k.w, 64, 64, tid), sv.load(Lw.v.w, 64, 64, tid);
+    so.load(Lw.out.w, 64, 64, tid);
+    vo.load(Lw.out.b, 64, tid), vg.load(Lw.attn_norm_w, 64, tid), vb.load(Lw.attn_norm_b, 64, tid);
+    sq.store(Wq, LDW, tid), sk.store(Wk, LDW, tid), sv.store(Wv, LDW, tid), so.store(Wo, LDW, tid);
+    vo.store(bO, tid), vg.store(gam, tid), vb.store(bet, tid);
+  }
   __syncthreads();
   const int j = lane & 15, g = lane >> 4;
   const int slot = wave / NT, t = wave - slot * NT;

@@ -441,3 +441,124 @@ __device__ __forceinline__ void stage_w(float* dst, int ldw, const float* __rest
     else stage_padded(dst, ldw, prow, 16 * kt, src, rows, cols, tid, nthreads);
   }
 }
+
+// ====================================================================================== two-phase staging
+// A kernel prologue that stages its matrices one after the other (load, wait, store to LDS, next
+// matrix) pays one global-memory round trip per matrix: measured 11 us (k_ff, 6 pieces) to ~40 us
+// (k_view_attn, 15 pieces) of fixed cost per launch.  These stagers split every piece into a load()
+// that only issues global loads into registers and a store() that converts and writes the LDS
+// image: a prologue calls every load() first, then every store(), and pays ONE round trip.
+// Same images as stage_w / stage_padded / stage_vector above (PROW, KT as there; NTHR = block size).
+template <int PROW, int PC4, int NTHR>
+struct RowStage {  // fp32 row-major image [PROW][ldw], PC4 16-byte columns, zero-padded
+  static constexpr int TOTAL = PROW * PC4, IT = (TOTAL + NTHR - 1) / NTHR;
+  f4 a[IT];
+  __device__ __forceinline__ void load(const float* __restrict__ src, int rows, int cols, int tid) {
+    const bool vec = (cols & 3) == 0;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int idx = tid + it * NTHR;
+      a[it] = f4_zero();
+      if (idx < TOTAL) {
+        const int r = idx / PC4, c = 4 * (idx - r * PC4);
+        if (r < rows) {
+          const float* p = src + (size_t)r * cols + c;
+          if (vec) {
+            if (c < cols) a[it] = ld4(p);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (c + e < cols) a[it][e] = p[e];
+          }
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float* dst, int ldw, int tid) const {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int idx = tid + it * NTHR;
+      if (idx < TOTAL) {
+        const int r = idx / PC4, c = 4 * (idx - r * PC4);
+        st4(dst + r * ldw + c, a[it]);
+      }
+    }
+  }
+};
+
+template <int PROW, int KT, int NTHR>
+struct SplitStage {  // bf16x3 fragment-major image (stage_split)
+  static constexpr int KP = (KT + 1) / 2, UPR = KP * 4, TOTAL = PROW * UPR, IT = (TOTAL + NTHR - 1) / NTHR;
+  f4 a[IT], b[IT];
+  __device__ __forceinline__ void load(const float* __restrict__ src, int rows, int cols, int tid) {
+    const bool vec = (cols & 3) == 0;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int idx = tid + it * NTHR;
+      a[it] = f4_zero(), b[it] = f4_zero();
+      if (idx < TOTAL) {
+        const int row = idx / UPR, u = idx - row * UPR, P = u >> 2, g = u & 3;
+        if (row < rows) {
+          const int c0 = 32 * P + 4 * g, c1 = c0 + 16;
+          const float* r = src + (size_t)row * cols;
+          if (vec) {
+            if (c0 < cols) a[it] = ld4(r + c0);
+            if (c1 < cols) b[it] = ld4(r + c1);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (c0 + e < cols) a[it][e] = r[c0 + e];
+              if (c1 + e < cols) b[it][e] = r[c1 + e];
+            }
+          }
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float* dstf, int /*ldw*/, int tid) const {
+    bf8* dst = reinterpret_cast<bf8*>(dstf);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int idx = tid + it * NTHR;
+      if (idx < TOTAL) {
+        const int row = idx / UPR, u = idx - row * UPR, P = u >> 2, g = u & 3;
+        const XS s = split8(a[it], b[it]);
+        const int blk = (((row >> 4) * KP + P) * 2) * 64 + 16 * g + (row & 15);
+        dst[blk] = s.hi;
+        dst[blk + 64] = s.mid;
+      }
+    }
+  }
+};
+
+template <bool SP, int PROW, int KT, int NTHR>
+struct WStageSel {
+  typedef RowStage<PROW, 4 * KT, NTHR> type;
+};
+template <int PROW, int KT, int NTHR>
+struct WStageSel<true, PROW, KT, NTHR> {
+  typedef SplitStage<PROW, KT, NTHR> type;
+};
+// image of a [rows, cols] matrix zero-padded to [PROW, 16*KT] in either mode (stage_w)
+template <bool SP, int PROW, int KT, int NTHR>
+using WStage = typename WStageSel<SP, PROW, KT, NTHR>::type;
+
+template <int PADDED, int NTHR>
+struct VecStage {  // stage_vector
+  static constexpr int IT = (PADDED + NTHR - 1) / NTHR;
+  float v[IT];
+  __device__ __forceinline__ void load(const float* __restrict__ src, int n, int tid) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int i = tid + it * NTHR;
+      v[it] = (src != nullptr && i < n && i < PADDED) ? src[i] : 0.0f;
+    }
+  }
+  __device__ __forceinline__ void store(float* dst, int tid) const {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int i = tid + it * NTHR;
+      if (i < PADDED) dst[i] = v[it];
+    }
+  }
+};

@@ -92,7 +92,7 @@ _SIGS = {
     "gpn_argmax_labels": (C.c_int, [_P, C.c_int, C.c_longlong, _P, _P, _P]),
     "gpn_repack_nhwc": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "gpn_project_gather": (C.c_int, [C.POINTER(ProjectArgs), _P]),
-    "gpn_posenc": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
+    "gpn_posenc": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "gpn_rgbfeat": (C.c_int, [C.POINTER(Linear), C.POINTER(Linear), _P, C.c_int, C.c_int, C.c_int,
                               C.c_int, _P, _P, _P, _P]),
     "gpn_view_attn": (C.c_int, [C.POINTER(ViewLayer), _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P,
@@ -101,7 +101,7 @@ _SIGS = {
     "gpn_vis_order_scratch_bytes": (C.c_size_t, []),
     "gpn_vis_order": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P]),
     "gpn_ff": (C.c_int, [_P, _P, C.POINTER(Linear), C.POINTER(Linear), _P, C.c_int, _P, _P]),
-    "gpn_qpos": (C.c_int, [C.POINTER(Linear), C.POINTER(Linear), _P, _P, C.c_int, _P, _P]),
+    "gpn_qpos": (C.c_int, [C.POINTER(Linear), C.POINTER(Linear), _P, _P, _P, C.c_int, C.c_int, _P, _P]),
     "gpn_ray_attn": (C.c_int, [C.POINTER(RayLayer), _P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P]),
     "gpn_sem_aggregate": (C.c_int, [C.POINTER(SemArgs), _P]),
     "gpn_heads": (C.c_int, [C.POINTER(GntWeights), _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P,

@@ -76,21 +76,28 @@ static int persistent_grid(long long work_items) {
 }
 
 // ------------------------------------------------------------------------------------ posenc
+// The 126 + 2 columns that q_fcs concatenates to q are stored in two pieces (same column order):
+//   emb_pt  [N, 64]  = posenc(pts) (63) | first view-encoding value (the normalised direction's x)
+//   emb_ray [R, 64]  = the other 62 view-encoding values | 0 0
+// The view encoding depends on the ray only: k_qpos reads it from the (cached) per-ray row instead
+// of 256 more bytes per point.
 __global__ void k_posenc(const float* __restrict__ pts, const float* __restrict__ ray_d, int S,
-                         long long N, float* __restrict__ emb) {
+                         long long N, long long R, float* __restrict__ emb_pt,
+                         float* __restrict__ emb_ray) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= N * GPN_EMB) return;
-  const long long n = idx >> 7;
-  const int c = (int)(idx & 127);
+  if (idx >= (N + R) * GPN_EMB_HALF) return;
+  const bool ray_part = idx >= N * GPN_EMB_HALF;
+  const long long row = (ray_part ? idx - N * GPN_EMB_HALF : idx) >> 6;
+  const int c = (int)(idx & 63) + (ray_part ? 64 : 0);  // column of the 128-wide concatenation
   float val = 0.0f;
   if (c < 126) {
     float sx, sy, sz;
     int k;
     if (c < 63) {
-      sx = pts[n * 3 + 0], sy = pts[n * 3 + 1], sz = pts[n * 3 + 2];
+      sx = pts[row * 3 + 0], sy = pts[row * 3 + 1], sz = pts[row * 3 + 2];
       k = c;
     } else {
-      const long long r = n / S;
+      const long long r = ray_part ? row : row / S;
       const float dx = ray_d[r * 3 + 0], dy = ray_d[r * 3 + 1], dz = ray_d[r * 3 + 2];
       const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
       sx = dx / nrm, sy = dy / nrm, sz = dz / nrm;
@@ -104,7 +111,7 @@ __global__ void k_posenc(const float* __restrict__ pts, const float* __restrict_
       val = rem >= 3 ? cosf(arg) : sinf(arg);
     }
   }
-  emb[idx] = val;
+  (ray_part ? emb_ray : emb_pt)[(row << 6) + (idx & 63)] = val;
 }
 
 // ------------------------------------------------------------------------------------ rgbfeat
@@ -1001,7 +1008,7 @@ k_ff(const float* __restrict__ norm_w, const float* __restrict__ norm_b, gpn_lin
 }
 
 // ------------------------------------------------------------------------------------ q positional MLP
-// input = [q (64) | emb (126 + 2 zero pad)] = 192 channels; LDS: W0 [64][196] | W2 [64][68] | b0 | b2
+// input = [q (64) | emb_pt (64) | emb_ray of the point's ray (64)] = 192 channels (k_posenc); LDS: W0 [64][196] | W2 [64][68] | b0 | b2
 #define QP_LD0 196
 constexpr int qp_lds_floats(bool spl) {
   return wimg_floats(spl, 64, 12, QP_LD0) + wimg_floats(spl, 64, 4, LDW) + 128;
@@ -1010,7 +1017,8 @@ constexpr int qp_lds_floats(bool spl) {
 template <bool SPL>
 __global__ void __launch_bounds__(QP_TPB)
 k_qpos(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ q_in,
-       const float* __restrict__ emb, long long N, float* __restrict__ q_out) {
+       const float* __restrict__ emb_pt, const float* __restrict__ emb_ray, long long N, int S,
+       float* __restrict__ q_out) {
   float* W0 = smem;
   float* W2 = W0 + wimg_floats(SPL, 64, 12, QP_LD0);
   float* b0 = W2 + wimg_floats(SPL, 64, 4, LDW);
@@ -1039,7 +1047,10 @@ k_qpos(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ q_in,
 #pragma unroll
     for (int T = 0; T < 4; ++T) x[T] = ld4(q_in + (size_t)nc * C64 + 16 * T + 4 * g);
 #pragma unroll
-    for (int T = 0; T < 8; ++T) x[4 + T] = ld4(emb + (size_t)nc * GPN_EMB + 16 * T + 4 * g);
+    for (int T = 0; T < 4; ++T) x[4 + T] = ld4(emb_pt + (size_t)nc * GPN_EMB_HALF + 16 * T + 4 * g);
+    const int ray = (int)nc / S;  // N fits an int (C-ABI)
+#pragma unroll
+    for (int T = 0; T < 4; ++T) x[8 + T] = ld4(emb_ray + (size_t)ray * GPN_EMB_HALF + 16 * T + 4 * g);
 #pragma unroll
     for (int M = 0; M < 4; ++M) h[M] = ld4(b0 + 16 * M + 4 * g);
     lin<SPL, 12, 4>(W0, QP_LD0, x, h, lane);
@@ -1649,16 +1660,16 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 #define REQ_LIN(l, name) \
   GPN_REQUIRE((l).w && aligned16((l).w), "%s: weight pointer null or not 16-byte aligned", name)
 
-extern "C" int gpn_posenc(const float* pts, const float* ray_d, int R, int S, float* emb,
-                          gpn_stream_t stream) {
+extern "C" int gpn_posenc(const float* pts, const float* ray_d, int R, int S, float* emb_pt,
+                          float* emb_ray, gpn_stream_t stream) {
   if (R == 0) return GPN_OK;  // empty batch (pointers may be null)
-  GPN_REQUIRE(pts && ray_d && emb, "gpn_posenc: null pointer");
+  GPN_REQUIRE(pts && ray_d && emb_pt && emb_ray, "gpn_posenc: null pointer");
   GPN_REQUIRE(R >= 0 && S >= 1, "gpn_posenc: bad shape");
   const long long N = (long long)R * S;
   if (N == 0) return GPN_OK;
   GpnStageTimer timer_k_posenc_(GPN_ST_POSENC, (hipStream_t)stream);
-  hipLaunchKernelGGL(k_posenc, dim3(gpn_ceil_div(N * GPN_EMB, 256)), dim3(256), 0,
-                     (hipStream_t)stream, pts, ray_d, S, N, emb);
+  hipLaunchKernelGGL(k_posenc, dim3(gpn_ceil_div((N + R) * GPN_EMB_HALF, 256)), dim3(256), 0,
+                     (hipStream_t)stream, pts, ray_d, S, N, (long long)R, emb_pt, emb_ray);
   GPN_LAUNCH_CHECK("k_posenc");
   return GPN_OK;
 }
@@ -1794,14 +1805,15 @@ extern "C" int gpn_ff(const float* norm_w, const float* norm_b, const gpn_linear
 }
 
 extern "C" int gpn_qpos(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* q_in,
-                        const float* emb, int N, float* q_out, gpn_stream_t stream) {
+                        const float* emb_pt, const float* emb_ray, int N, int S, float* q_out,
+                        gpn_stream_t stream) {
   if (N == 0) return GPN_OK;  // empty batch (pointers may be null)
-  GPN_REQUIRE(fc0 && fc2 && q_in && emb && q_out, "gpn_qpos: null pointer");
+  GPN_REQUIRE(fc0 && fc2 && q_in && emb_pt && emb_ray && q_out, "gpn_qpos: null pointer");
   GPN_REQUIRE(fc0->w, "gpn_qpos: null weight");
   REQ_LIN(*fc2, "gpn_qpos.fc2");
-  GPN_REQUIRE(aligned16(q_in) && aligned16(emb) && aligned16(q_out),
+  GPN_REQUIRE(aligned16(q_in) && aligned16(emb_pt) && aligned16(emb_ray) && aligned16(q_out),
               "gpn_qpos: tensors must be 16-byte aligned");
-  GPN_REQUIRE(N >= 0, "gpn_qpos: bad N");
+  GPN_REQUIRE(N >= 0 && S >= 1 && N % S == 0, "gpn_qpos: N must be a multiple of S >= 1 (got N=%d S=%d)", N, S);
   if (N == 0) return GPN_OK;
   const bool spl = gpn_precision() == GPN_PREC_BF16X3;
   const size_t lds = sizeof(float) * qp_lds_floats(spl);
@@ -1811,11 +1823,11 @@ extern "C" int gpn_qpos(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const 
   const int grid = persistent_grid(((long long)N + (QP_TPB / 4) - 1) / (QP_TPB / 4));
   GpnStageTimer timer_k_qpos_(GPN_ST_QPOS, (hipStream_t)stream);
   if (spl)
-    hipLaunchKernelGGL(k_qpos<true>, dim3(grid), dim3(QP_TPB), lds, (hipStream_t)stream, *fc0, *fc2, q_in, emb,
-                     (long long)N, q_out);
+    hipLaunchKernelGGL(k_qpos<true>, dim3(grid), dim3(QP_TPB), lds, (hipStream_t)stream, *fc0, *fc2, q_in, emb_pt,
+                     emb_ray, (long long)N, S, q_out);
   else
-    hipLaunchKernelGGL(k_qpos<false>, dim3(grid), dim3(QP_TPB), lds, (hipStream_t)stream, *fc0, *fc2, q_in, emb,
-                     (long long)N, q_out);
+    hipLaunchKernelGGL(k_qpos<false>, dim3(grid), dim3(QP_TPB), lds, (hipStream_t)stream, *fc0, *fc2, q_in, emb_pt,
+                     emb_ray, (long long)N, S, q_out);
   GPN_LAUNCH_CHECK("k_qpos");
   return GPN_OK;
 }
@@ -1938,13 +1950,14 @@ extern "C" int gpn_heads(const gpn_gnt_weights_t* W, const float* q, const float
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct GntWs {
-  size_t emb, feat, q, hidden, stats, abar, weights, pre, perm, vis_scratch, total;
+  size_t emb, emb_ray, feat, q, hidden, stats, abar, weights, pre, perm, vis_scratch, total;
 };
 static GntWs gnt_ws_layout(int R, int S, int V, int depth) {
   const size_t N = (size_t)R * S, f = sizeof(float);
   GntWs w;
   size_t o = 0;
-  w.emb = o, o += align_up(N * GPN_EMB * f);
+  w.emb = o, o += align_up(N * GPN_EMB_HALF * f);
+  w.emb_ray = o, o += align_up((size_t)R * GPN_EMB_HALF * f);
   w.feat = o, o += align_up(N * V * C64 * f);
   w.q = o, o += align_up(N * C64 * f);
   w.hidden = o, o += align_up(N * V * depth * 8 * f);    // [N,V,depth,8]
@@ -1985,6 +1998,7 @@ extern "C" int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat
   char* ws = static_cast<char*>(workspace);
   const size_t N = (size_t)R * S;
   float* emb = reinterpret_cast<float*>(ws + L.emb);
+  float* emb_ray = reinterpret_cast<float*>(ws + L.emb_ray);
   float* feat = reinterpret_cast<float*>(ws + L.feat);
   float* q = reinterpret_cast<float*>(ws + L.q);
   float* wts = reinterpret_cast<float*>(ws + L.weights);
@@ -1992,7 +2006,7 @@ extern "C" int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat
   int32_t* perm = reinterpret_cast<int32_t*>(ws + L.perm);
   int rc;
   if ((rc = gpn_vis_order(mask, (int)N, V, perm, ws + L.vis_scratch, stream))) return rc;
-  if ((rc = gpn_posenc(pts, ray_d, R, S, emb, stream))) return rc;
+  if ((rc = gpn_posenc(pts, ray_d, R, S, emb, emb_ray, stream))) return rc;
   // (mask given: the feature rows of masked pairs, which gpn_view_attn never uses, are not stored)
   if ((rc = gpn_rgbfeat(&W->rgbfeat0, &W->rgbfeat2, rgb_feat, (int)N, V, 3 + W->in_feat_ch, rgb_feat_ld,
                         mask, feat, q, stream)))
@@ -2009,7 +2023,7 @@ extern "C" int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat
       return rc;
     if ((rc = gpn_ff(vl->ff_norm_w, vl->ff_norm_b, &vl->ff1, &vl->ff2, q, (int)N, q, stream))) return rc;
     if (l % 2 == 0)
-      if ((rc = gpn_qpos(&W->qfc0[l], &W->qfc2[l], q, emb, (int)N, q, stream))) return rc;
+      if ((rc = gpn_qpos(&W->qfc0[l], &W->qfc2[l], q, emb, emb_ray, (int)N, S, q, stream))) return rc;
     if ((rc = gpn_ray_attn(rl, q, R, S, q, ab, D * 4, l == D - 1 ? wts : nullptr, stream))) return rc;
     if ((rc = gpn_ff(rl->ff_norm_w, rl->ff_norm_b, &rl->ff1, &rl->ff2, q, (int)N, q, stream))) return rc;
   }

@@ -31,7 +31,8 @@ extern "C" {
 
 #define GPN_C 64         /* netwidth (reference config.py:108) */
 #define GPN_SEM 512      /* deep-semantic channels (hard-coded in reference render_image.py:95) */
-#define GPN_EMB 128      /* pos-enc(63) + view-enc(63) + 2 zero pad, per point */
+#define GPN_EMB 128      /* pos-enc(63) + view-enc(63) + 2 zero pad: the columns q_fcs adds to q */
+#define GPN_EMB_HALF 64  /* ... stored as a per-point half and a per-ray half (gpn_posenc) */
 #define GPN_MAX_DEPTH 8  /* trans_depth (reference configs/gpnerf_*.txt) */
 #define GPN_MAX_VIEWS 32
 #define GPN_MAX_SAMPLES 128
@@ -163,9 +164,13 @@ typedef struct {                 /* GNT, transformer_network.py:221-294 (state-d
   gpn_linear_t sem_adaptor;              /* [512,512] */
 } gpn_gnt_weights_t;
 
-/* Embedder x2, transformer_network.py:6-37 and :297-306.  emb [N,GPN_EMB] =
- * [posenc(pts) 63 | posenc(ray_d/|ray_d|) 63 | 0 0]. */
-int gpn_posenc(const float* pts, const float* ray_d, int R, int S, float* emb, gpn_stream_t stream);
+/* Embedder x2, transformer_network.py:6-37 and :297-306.  The GPN_EMB columns
+ * [posenc(pts) 63 | posenc(ray_d/|ray_d|) 63 | 0 0] that q_fcs concatenates to q (:322-323) are
+ * stored in two halves, in that column order: emb_pt [N,64] = columns 0..63 of every point,
+ * emb_ray [R,64] = columns 64..127, which depend on the ray only (the reference broadcasts the view
+ * encoding over the samples, :304-306). */
+int gpn_posenc(const float* pts, const float* ray_d, int R, int S, float* emb_pt, float* emb_ray,
+               gpn_stream_t stream);
 
 /* rgbfeat_fc + max over views, transformer_network.py:309-311.
  * rgb_feat [N,V,3+F] -> feat [N,V,C], q0 [N,C].
@@ -225,9 +230,10 @@ int gpn_vis_order(const float* mask, int N, int V, int32_t* perm, void* scratch,
 int gpn_ff(const float* norm_w, const float* norm_b, const gpn_linear_t* fc1,
            const gpn_linear_t* fc2, const float* x_in, int N, float* x_out, gpn_stream_t stream);
 
-/* q_fcs[i] on cat(q, pos-enc, view-enc), transformer_network.py:322-324. q [N,C], emb [N,128]. */
-int gpn_qpos(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* q_in, const float* emb,
-             int N, float* q_out, gpn_stream_t stream);
+/* q_fcs[i] on cat(q, pos-enc, view-enc), transformer_network.py:322-324. q [N,C], emb_pt [N,64],
+ * emb_ray [N/S,64] (gpn_posenc); point n belongs to ray n / S. */
+int gpn_qpos(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* q_in, const float* emb_pt,
+             const float* emb_ray, int N, int S, float* q_out, gpn_stream_t stream);
 
 /* Attention part of the ray Transformer, transformer_network.py:149-178 and :203-208.
  * x_in [R,S,C] -> x_out [R,S,C]; abar = mean over queries of A per head (may be NULL): the 4 head

@@ -294,12 +294,14 @@ def test_gnt_stages(dev, net, prec, S):
     e = lambda *s: torch.empty(s, device=dev)
     errs = {}
     # posenc
-    emb = e(N, 128)
+    emb_pt, emb_ray = e(N, 64), e(R, 64)  # columns 0..63 per point, 64..127 per ray (gpn_posenc)
     pts_d, rayd_d, rgbf_d = f(c["pts"]), f(c["ray_d"]), f(c["rgb_feat"])  # keep alive: kernels are async
-    _lib.check(L.gpn_posenc(_lib.ptr(pts_d), _lib.ptr(rayd_d), R, S, _lib.ptr(emb), st), "posenc")
+    _lib.check(L.gpn_posenc(_lib.ptr(pts_d), _lib.ptr(rayd_d), R, S, _lib.ptr(emb_pt), _lib.ptr(emb_ray), st),
+               "posenc")
     want = torch.cat([rec["pos_enc"].reshape(N, 63),
                       rec["view_enc"][:, None].expand(R, S, 63).reshape(N, 63),
                       torch.zeros(N, 2)], -1)
+    emb = torch.cat([emb_pt, emb_ray[:, None].expand(R, S, 64).reshape(N, 64)], -1)
     errs["posenc"] = rel(emb, want)
     # rgbfeat
     feat, q0 = e(N, V, 64), e(N, 64)
@@ -322,7 +324,7 @@ def test_gnt_stages(dev, net, prec, S):
         "padded rows / masked stores changed a stored feature row"
     assert bool(torch.isnan(feat_m[~stored]).all()), "the feature row of a masked pair was stored"
     feat_ref = f(enc_feat(rec["feat"].reshape(N, V, 64), prec))
-    emb_ref = f(want)
+    emb_ref_pt, emb_ref_ray = f(want[:, :64]), f(want.reshape(R, S, 128)[:, 0, 64:])
     for l in (0, 1, 7):
         q_in = f((rec["q0"] if l == 0 else rec["q_ray"][l - 1]).reshape(N, 64))
         qo, hd, stt = e(N, 64), torch.zeros(N, V, 8, device=dev), e(N, 64)
@@ -384,7 +386,7 @@ def test_gnt_stages(dev, net, prec, S):
             q3 = e(N, 64)
             qp_in = f(rec["q_view"][l].reshape(N, 64))
             _lib.check(L.gpn_qpos(C.byref(W.qfc0[l]), C.byref(W.qfc2[l]), _lib.ptr(qp_in),
-                                  _lib.ptr(emb_ref), N, _lib.ptr(q3), st), "qpos")
+                                  _lib.ptr(emb_ref_pt), _lib.ptr(emb_ref_ray), N, S, _lib.ptr(q3), st), "qpos")
             errs["qpos%d" % l] = rel(q3, rec["q_pos"][l // 2].reshape(N, 64))
             x_in = rec["q_pos"][l // 2]
         else:
@@ -424,6 +426,7 @@ def test_gnt_stages_many_tiles(dev, net, prec):
     mask[3::11, 1::3] = 1.0       # points visible everywhere
     rgbf = torch.randn(R, S, V, 35, generator=gcpu)
     emb = torch.randn(N, 128, generator=gcpu)
+    emb[:, 64:] = emb.reshape(R, S, 128)[:, :1, 64:].expand(R, S, 64).reshape(N, 64)  # view half: per ray
     emb[:, 126:] = 0.0
     W = net._weights()
     st = _lib.stream()
@@ -490,9 +493,9 @@ def test_gnt_stages_many_tiles(dev, net, prec):
     # q positional MLP (layer 0)
     xin = torch.cat([q.reshape(N, 64), emb[:, :126]], -1)
     want = oracle.gnt._lin(sd, "q_fcs.0.2", F.relu(oracle.gnt._lin(sd, "q_fcs.0.0", xin)))
-    out, emb_d = e(N, 64), f(emb)
-    _lib.check(L.gpn_qpos(C.byref(W.qfc0[0]), C.byref(W.qfc2[0]), _lib.ptr(qd), _lib.ptr(emb_d), N,
-                          _lib.ptr(out), st), "qpos")
+    out, emb_p, emb_r = e(N, 64), f(emb[:, :64]), f(emb.reshape(R, S, 128)[:, 0, 64:])
+    _lib.check(L.gpn_qpos(C.byref(W.qfc0[0]), C.byref(W.qfc2[0]), _lib.ptr(qd), _lib.ptr(emb_p),
+                          _lib.ptr(emb_r), N, S, _lib.ptr(out), st), "qpos")
     errs["qpos"] = rel(out, want)
     # ray attention (layer 0)
     pr = "view_selftrans.0"

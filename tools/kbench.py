@@ -22,11 +22,11 @@ V = 10
 for N in (128, 32768, 131072, 262144):
     q = torch.randn(N, 64, device=dev); qo = torch.empty_like(q)
     feat = torch.randn(N, V, 64, device=dev); rd = torch.randn(N, V, 4, device=dev)
-    mask = torch.ones(N, V, device=dev); emb = torch.randn(N, 128, device=dev)
+    mask = torch.ones(N, V, device=dev); emb = torch.randn(N, 64, device=dev)
     vl = W.view[0]
     t_ff = timeit(lambda: L.gpn_ff(vl.ff_norm_w, vl.ff_norm_b, C.byref(vl.ff1), C.byref(vl.ff2), _lib.ptr(q), N, _lib.ptr(qo), st))
     t_va = timeit(lambda: L.gpn_view_attn(C.byref(vl), _lib.ptr(q), _lib.ptr(feat), _lib.ptr(rd), _lib.ptr(mask), None, N, V, _lib.ptr(qo), None, 64, None, 64, st))
-    t_qp = timeit(lambda: L.gpn_qpos(C.byref(W.qfc0[0]), C.byref(W.qfc2[0]), _lib.ptr(q), _lib.ptr(emb), N, _lib.ptr(qo), st))
+    t_qp = timeit(lambda: L.gpn_qpos(C.byref(W.qfc0[0]), C.byref(W.qfc2[0]), _lib.ptr(q), _lib.ptr(emb), _lib.ptr(emb), N, 64, _lib.ptr(qo), st))
     S = 64; R = max(1, N // S)
     x = torch.randn(R, S, 64, device=dev); xo = torch.empty_like(x); ab = torch.empty(R, S, 4, device=dev)
     t_ra = timeit(lambda: L.gpn_ray_attn(C.byref(W.ray[0]), _lib.ptr(x), R, S, _lib.ptr(xo), _lib.ptr(ab), 4, None, st))

@@ -51,12 +51,34 @@ extern __shared__ __attribute__((aligned(16))) float smem[];
 // thread 0 of workgroup 0 at marked places of a kernel, read back with gpn_debug_stamps.
 #ifdef GPN_STAMP
 __device__ unsigned long long g_stamps[64];
-#define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[i] = wall_clock64(); } while (0)
+#define STAMP(i) do { if (threadIdx.x == 0) { \
+    if (blockIdx.x == 0) { g_stamps[i] = wall_clock64(); g_stamps[32 + (i)] = __builtin_readcyclecounter(); } \
+    if (blockIdx.x == gridDim.x - 1) g_stamps[16 + (i)] = wall_clock64(); \
+    if (blockIdx.x == gridDim.x / 2 + 3) g_stamps[48 + (i)] = wall_clock64(); } } while (0)
+// per-wave start / end stamps of one kernel (no atomics: one slot per wave), up to 4096 waves
+__device__ unsigned long long g_wave_t[2][4096];
+#define WAVE_T(which) do { if ((threadIdx.x & 63) == 0) { const unsigned w_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); \
+    if (w_ < 4096) g_wave_t[which][w_] = wall_clock64(); } } while (0)
+extern "C" int gpn_debug_wave_times(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_t), sizeof(g_wave_t)) == hipSuccess ? 0 : 1;
+}
+// earliest / latest stamp over every wave of the grid (slots 60 / 61)
+#define STAMP_MIN() do { if ((threadIdx.x & 63) == 0) atomicMin(&g_stamps[60], (unsigned long long)wall_clock64()); } while (0)
+#define STAMP_MAX() do { if ((threadIdx.x & 63) == 0) { const unsigned long long t_ = wall_clock64(); \
+    atomicMax(&g_stamps[61], t_); atomicMax(&g_stamps[52 + (blockIdx.x & 7)], t_); } } while (0)
 extern "C" int gpn_debug_stamps(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : 1;
 }
+extern "C" int gpn_debug_stamps_reset(void) {
+  unsigned long long z[64] = {0};
+  z[60] = ~0ull;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) == hipSuccess ? 0 : 1;
+}
 #else
 #define STAMP(i) do { } while (0)
+#define STAMP_MIN() do { } while (0)
+#define STAMP_MAX() do { } while (0)
+#define WAVE_T(which) do { } while (0)
 #endif
 
 
@@ -898,6 +920,7 @@ k_ff(const float* __restrict__ norm_w, const float* __restrict__ norm_b, gpn_lin
   float* bet = gam + 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   STAMP(8);
+  WAVE_T(0);
   {  // two-phase staging (gnt_mfma.h): every global load first, then the LDS images
     WStage<SPL, 256, 4, FF_TPB> s1;
     WStage<SPL, 64, 16, FF_TPB> s2;
@@ -976,11 +999,13 @@ k_ff(const float* __restrict__ norm_w, const float* __restrict__ norm_b, gpn_lin
         if (n[t] < N) {
 #pragma unroll
           for (int M = 0; M < 4; ++M) {
-            st4(x_out + (size_t)n[t] * C64 + 16 * M + 4 * g, y[t][M] + x[t][M]);
+            FF_ST(x_out + (size_t)n[t] * C64 + 16 * M + 4 * g, y[t][M] + x[t][M]);
           }
         }
       }
     }
+    STAMP(11);
+    WAVE_T(1);
   } else {
     for (long long tile = (long long)blockIdx.x * (FF_TPB / 64) + wave; tile < ntiles;
          tile += (long long)gridDim.x * (FF_TPB / 64)) {

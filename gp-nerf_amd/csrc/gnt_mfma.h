@@ -63,6 +63,19 @@ __device__ __forceinline__ void st4_nt(float* p, f4 v) { *reinterpret_cast<f4*>(
 __device__ __forceinline__ void st4_nt(float* p, f4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f4*>(p)); }
 #endif
 
+// write-through store (sc0 sc1: the line does not stay dirty in this XCD's L2, so the release at the
+// end of the kernel has nothing of it left to write back)
+__device__ __forceinline__ void st4_wt(float* p, f4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+#if defined(GPN_FF_ST) && GPN_FF_ST == 1
+#define FF_ST st4_nt
+#elif defined(GPN_FF_ST) && GPN_FF_ST == 2
+#define FF_ST st4_wt
+#else
+#define FF_ST st4
+#endif
+
 // y[M] += W[16M.., 16T..] . x[T]   (transposed orientation: x, y are T-tiles; W row-major in LDS with
 // leading dimension ldw floats).  y must be initialised (bias or zero) by the caller.
 template <int KT, int MT>

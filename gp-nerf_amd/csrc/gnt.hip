@@ -74,7 +74,15 @@ extern "C" int gpn_debug_stamps_reset(void) {
   z[60] = ~0ull;
   return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) == hipSuccess ? 0 : 1;
 }
+// shader-cycle stamps inside one wave's second tile iteration of k_ff32 (slot k = region boundary k)
+__device__ unsigned long long g_ffc[4][32];
+#define FFC(k) do { if (ffc_on) { const unsigned long long t_ = __builtin_readcyclecounter(); \
+    if (lane == 0) g_ffc[wave & 3][k] = t_; } __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int gpn_debug_ffc(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ffc), sizeof(g_ffc)) == hipSuccess ? 0 : 1;
+}
 #else
+#define FFC(k) do { } while (0)
 #define STAMP(i) do { } while (0)
 #define STAMP_MIN() do { } while (0)
 #define STAMP_MAX() do { } while (0)
@@ -1032,6 +1040,192 @@ k_ff(const float* __restrict__ norm_w, const float* __restrict__ norm_b, gpn_lin
   }
 }
 
+// Split-mode feed-forward on 32x32x16 MFMAs (gnt_mfma.h, "32x32x16 form"): one 32-point tile per wave
+// iteration, 192 MFMAs of 32 cycles per tile -- the pipe time of the 16x16x32 kernel above at half the
+// MFMA issue slots and 40 % fewer vector instructions.  The residual rides in the accumulator (y starts
+// as x + b2), the hidden layer is produced and consumed in eight 32-wide chunks.  Same LDS budget:
+// W1, W2 images 64 KB each.
+// NOT the default (-DGPN_FF32=1 selects it): parity-green, but measured equal to k_ff<true> in a
+// back-to-back microbench (52-57 us vs 51-55 us at N = 262144) and 0.7 % slower on the whole step.
+// Ablations (tools/ffbench.py, results in DESIGN.md section 6): dropping the whole ReLU + operand
+// split and every in-loop LDS weight read only takes 57 -> 50 us; the slope is 45 us per 262144
+// points where the MFMA pipe time is 22 us, in both tilings.
+#ifndef GPN_FF32
+#define GPN_FF32 0
+#endif
+
+__device__ __forceinline__ f4 v16_get(const f16v& v, int b) {
+  return (f4){v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3]};
+}
+__device__ __forceinline__ void v16_set(f16v& v, int b, f4 t) {
+  v[4 * b] = t.x, v[4 * b + 1] = t.y, v[4 * b + 2] = t.z, v[4 * b + 3] = t.w;
+}
+
+// weight fragments of the first layer, hidden channels 32c .. 32c+31: [K-step s][hi, mid]
+__device__ __forceinline__ void ff32_w1(const bf8* w1p, int c, bf8 (&w)[8]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    w[2 * s] = w1p[((c * 4 + s) * 2) * 64];
+    w[2 * s + 1] = w1p[((c * 4 + s) * 2 + 1) * 64];
+  }
+}
+// first layer, hidden channels 32c .. 32c+31 of the wave's 32 points: h = b1 + W1[32c.., :] . xn
+__device__ __forceinline__ void ff32_fc1(const float* b1, int c, int gg, const bf8 (&w)[8], const XS (&xs)[4], f16v& h) {
+#pragma unroll
+  for (int b = 0; b < 4; ++b) v16_set(h, b, ld4(b1 + 32 * c + 8 * b + 4 * gg));
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    h = mfma_bf32(w[2 * s + 1], xs[s].hi, h);
+    h = mfma_bf32(w[2 * s], xs[s].mid, h);
+    h = mfma_bf32(w[2 * s], xs[s].hi, h);
+  }
+}
+
+// one 32-point input tile (rows clamped to the last point)
+__device__ __forceinline__ void ff32_load(const float* __restrict__ x_in, long long np, long long N, int gg, f4 (&x)[2][4]) {
+  const long long npc = np < N ? np : N - 1;
+#pragma unroll
+  for (int M = 0; M < 2; ++M)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) x[M][b] = ld4(x_in + (size_t)npc * C64 + 32 * M + 8 * b + 4 * gg);
+}
+// LayerNorm over the 64 channels of a point (32 registers of this lane + the partner lane gg ^ 1),
+// split into the B fragments of the first layer
+__device__ __forceinline__ void ff32_ln(const f4 (&x)[2][4], const float* gam, const float* bet, int gg, XS (&xs)[4]) {
+  float sm = 0.f;
+#pragma unroll
+  for (int M = 0; M < 2; ++M)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) sm += (x[M][b].x + x[M][b].y) + (x[M][b].z + x[M][b].w);
+  sm += __shfl_xor(sm, 32);
+  const float mean = sm * (1.0f / 64.0f);
+  float sq = 0.f;
+#pragma unroll
+  for (int M = 0; M < 2; ++M)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const f4 d = x[M][b] - f4_splat(mean);
+      sq += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    }
+  sq += __shfl_xor(sq, 32);
+  const float rstd = __builtin_amdgcn_rsqf(sq * (1.0f / 64.0f) + 1e-6f);
+#pragma unroll
+  for (int M = 0; M < 2; ++M) {
+    f4 xn[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int c = 32 * M + 8 * b + 4 * gg;
+      xn[b] = (x[M][b] - f4_splat(mean)) * f4_splat(rstd) * ld4(gam + c) + ld4(bet + c);
+    }
+    xs[2 * M] = split8(xn[0], xn[1]);
+    xs[2 * M + 1] = split8(xn[2], xn[3]);
+  }
+}
+
+__global__ void __launch_bounds__(FF_TPB)
+k_ff32(const float* __restrict__ norm_w, const float* __restrict__ norm_b, gpn_linear_t fc1,
+       gpn_linear_t fc2, const float* __restrict__ x_in, long long N, float* __restrict__ x_out) {
+  float* W1 = smem;
+  float* W2 = W1 + 256 * 64;
+  float* b1 = W2 + 64 * 256;
+  float* b2 = b1 + 256;
+  float* gam = b2 + 64;
+  float* bet = gam + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  {  // two-phase staging: every global load first, then the LDS images
+    SplitStage32<256, 4, FF_TPB> s1;
+    SplitStage32<64, 16, FF_TPB> s2;
+    VecStage<256, FF_TPB> v1;
+    VecStage<64, FF_TPB> v2, vg, vb;
+    s1.load(fc1.w, tid), s2.load(fc2.w, tid);
+    v1.load(fc1.b, 256, tid), v2.load(fc2.b, 64, tid), vg.load(norm_w, 64, tid), vb.load(norm_b, 64, tid);
+    s1.store(W1, tid), s2.store(W2, tid);
+    v1.store(b1, tid), v2.store(b2, tid), vg.store(gam, tid), vb.store(bet, tid);
+  }
+  __syncthreads();
+  const int i = lane & 31, gg = lane >> 5;
+  const bf8* w1p = reinterpret_cast<const bf8*>(W1) + lane;
+  const bf8* w2p = reinterpret_cast<const bf8*>(W2) + lane;
+  const long long ntiles = (N + 31) >> 5;
+  const long long stride = (long long)gridDim.x * (FF_TPB / 64);
+  long long tile = (long long)blockIdx.x * (FF_TPB / 64) + wave;
+  // lane (i, gg) holds channels 32M + 8b + 4gg + r of point 32 tile + i in x[M][b][r]
+  f4 xpre[2][4];
+  ff32_load(x_in, tile * 32 + i, N, gg, xpre);
+  // Pipelined across tiles: while the second-layer MFMAs of a tile's last chunks issue, the wave
+  // normalises and splits the NEXT tile's input (its registers are free once the last first-layer
+  // chunk has issued) and starts that tile's first hidden chunk -- no MFMA-free stretch per tile.
+  XS xs[4];  // K-step 2M + h of the first layer
+  bf8 w1f[8], w2f[8];
+  f16v hn;
+  ff32_ln(xpre, gam, bet, gg, xs);
+  ff32_w1(w1p, 0, w1f);
+  ff32_fc1(b1, 0, gg, w1f, xs, hn);
+  ff32_w1(w1p, 1, w1f);
+  __builtin_amdgcn_sched_barrier(0);
+  [[maybe_unused]] int ffc_it = 0;
+  for (; tile < ntiles; tile += stride) {
+    const long long n = tile * 32 + i;
+    [[maybe_unused]] const bool ffc_on = blockIdx.x == 7 && wave < 4 && ffc_it == 1;
+    ++ffc_it;
+    FFC(0);
+    f16v y[2];  // the residual rides in the accumulator
+#pragma unroll
+    for (int M = 0; M < 2; ++M)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) v16_set(y[M], b, xpre[M][b] + ld4(b2 + 32 * M + 8 * b + 4 * gg));
+    ff32_load(x_in, (tile + stride) * 32 + i, N, gg, xpre);  // the next tile's input, used from chunk 7 on
+    __builtin_amdgcn_sched_barrier(0);
+    FFC(1);
+    // eight 32-wide hidden chunks, two regions per chunk separated by sched_barriers.  Region A:
+    // first-layer MFMAs of chunk c + 1 next to the ReLU + operand split of chunk c; region B:
+    // second-layer MFMAs of chunk c.  Every region starts with its 8 weight fragments already in
+    // registers (read from LDS during the previous region) -- left to itself hipcc reads each
+    // fragment right before its MFMA and waits out the LDS latency 8 times a region.
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const f16v h = hn;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int My = 0; My < 2; ++My) {
+          w2f[(hh * 2 + My) * 2] = w2p[((My * 16 + 2 * c + hh) * 2) * 64];
+          w2f[(hh * 2 + My) * 2 + 1] = w2p[((My * 16 + 2 * c + hh) * 2 + 1) * 64];
+        }
+      if (c + 1 < 8) ff32_fc1(b1, c + 1, gg, w1f, xs, hn);
+      XS hs[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+        hs[hh] = split8(f4_relu_i(v16_get(h, 2 * hh)), f4_relu_i(v16_get(h, 2 * hh + 1)));
+      if (c == 7) ff32_ln(xpre, gam, bet, gg, xs);  // xs is dead since chunk 7's first layer issued
+      __builtin_amdgcn_sched_barrier(0);
+      FFC(2 + 2 * c);
+      if (c + 2 < 8) ff32_w1(w1p, c + 2, w1f);
+      else if (c == 6) ff32_w1(w1p, 0, w1f);
+      if (c == 7) ff32_fc1(b1, 0, gg, w1f, xs, hn);  // next tile, chunk 0
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {  // K-step 2c + hh of the second layer = 16 hidden channels
+#pragma unroll
+        for (int My = 0; My < 2; ++My) {
+          const bf8 wh = w2f[(hh * 2 + My) * 2], wm = w2f[(hh * 2 + My) * 2 + 1];
+          y[My] = mfma_bf32(wm, hs[hh].hi, y[My]);
+          y[My] = mfma_bf32(wh, hs[hh].mid, y[My]);
+          y[My] = mfma_bf32(wh, hs[hh].hi, y[My]);
+        }
+      }
+      if (c == 7) ff32_w1(w1p, 1, w1f);
+      __builtin_amdgcn_sched_barrier(0);
+      FFC(3 + 2 * c);
+    }
+    if (n < N) {
+#pragma unroll
+      for (int M = 0; M < 2; ++M)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) st4(x_out + (size_t)n * C64 + 32 * M + 8 * b + 4 * gg, v16_get(y[M], b));
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ q positional MLP
 // input = [q (64) | emb_pt (64) | emb_ray of the point's ray (64)] = 192 channels (k_posenc); LDS: W0 [64][196] | W2 [64][68] | b0 | b2
 #define QP_LD0 196
@@ -1819,7 +2013,13 @@ extern "C" int gpn_ff(const float* norm_w, const float* norm_b, const gpn_linear
   if (rc) return rc;
   const int grid = persistent_grid(((long long)N + (FF_TPB / 4) - 1) / (FF_TPB / 4));
   GpnStageTimer timer_k_ff_(GPN_ST_FF, (hipStream_t)stream);
-  if (spl)
+  if (spl && GPN_FF32) {
+    rc = set_lds_limit(reinterpret_cast<const void*>(k_ff32), lds);
+    if (rc) return rc;
+    const int grid32 = persistent_grid(((long long)N + (FF_TPB / 2) - 1) / (FF_TPB / 2));
+    hipLaunchKernelGGL(k_ff32, dim3(grid32), dim3(FF_TPB), lds, (hipStream_t)stream, norm_w, norm_b, *fc1,
+                       *fc2, x_in, (long long)N, x_out);
+  } else if (spl)
     hipLaunchKernelGGL(k_ff<true>, dim3(grid), dim3(FF_TPB), lds, (hipStream_t)stream, norm_w, norm_b, *fc1,
                      *fc2, x_in, (long long)N, x_out);
   else

@@ -52,6 +52,14 @@ __device__ __forceinline__ f4 f4_relu_t(f4 v) {
     return f4_relu(v);
   }
 }
+// max(x, 0) on the bit pattern: a negative float is a negative int, so one v_max_i32 does it -- no
+// canonicalising pre-pass, and a compiler-visible instruction (hipcc inserts the wait states a read of
+// an MFMA result needs; it does not for the asm form above)
+__device__ __forceinline__ float relu_i(float x) {
+  const int v = __builtin_bit_cast(int, x);
+  return __builtin_bit_cast(float, v > 0 ? v : 0);
+}
+__device__ __forceinline__ f4 f4_relu_i(f4 v) { return (f4){relu_i(v.x), relu_i(v.y), relu_i(v.z), relu_i(v.w)}; }
 __device__ __forceinline__ f4 f4_max(f4 a, f4 b) {
   return (f4){max_nc(a.x, b.x), max_nc(a.y, b.y), max_nc(a.z, b.z), max_nc(a.w, b.w)};
 }
@@ -454,6 +462,55 @@ __device__ __forceinline__ void stage_w(float* dst, int ldw, const float* __rest
     else stage_padded(dst, ldw, prow, 16 * kt, src, rows, cols, tid, nthreads);
   }
 }
+
+// ====================================================================================== 32x32x16 form
+// v_mfma_f32_32x32x16_bf16: D[32x32] += A[32x16] . B[16x32]; lane (i = l&31, gg = l>>5) supplies
+// A[row i][k = 8gg..8gg+7] and B[k = 8gg..8gg+7][col i] and holds D[row 8b + 4gg + r][col i] in
+// register 4b + r (b, r = 0..3).  Same flops per pipe cycle as the 16x16x32 form, but an MFMA holds
+// the SIMD's vector issue for 8 of its 32 cycles instead of 8 of its 16: half the issue slots per flop.
+// "T32-tile": 32 channels x 32 points, lane (i, gg) holds channels 32M + 8b + 4gg + r of point i.
+// Registers 8h..8h+7 of an output tile are then the B fragment of K-step 2M + h of the next layer
+// (k slots 8gg + e <-> channels 32M + 16h + 4gg + {0..3, 8..11}); the weight image stores its A
+// fragments in that column order, fragment-major:
+//   unit(row 32Mo + i, K-step s, piece hm, gg) at ((Mo*KS + s)*2 + hm)*64 + 32gg + i
+typedef float f16v __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f16v mfma_bf32(bf8 a, bf8 b, f16v c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int PROW, int KS, int NTHR>
+struct SplitStage32 {  // exact [PROW, 16*KS] row-major fp32 matrix -> bf16x3 image for the 32x32x16 form
+  static constexpr int UPR = KS * 2, TOTAL = PROW * UPR, IT = (TOTAL + NTHR - 1) / NTHR;
+  static_assert(PROW % 32 == 0, "rows must fill whole 32-row tiles");
+  f4 a[IT], b[IT];
+  __device__ __forceinline__ void load(const float* __restrict__ src, int tid) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int idx = tid + it * NTHR;
+      a[it] = f4_zero(), b[it] = f4_zero();
+      if (idx < TOTAL) {
+        const int row = idx / UPR, u = idx - row * UPR, s = u >> 1, gg = u & 1;
+        const float* r = src + (size_t)row * (16 * KS) + 16 * s + 4 * gg;
+        a[it] = ld4(r);
+        b[it] = ld4(r + 8);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float* dstf, int tid) const {
+    bf8* dst = reinterpret_cast<bf8*>(dstf);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int idx = tid + it * NTHR;
+      if (idx < TOTAL) {
+        const int row = idx / UPR, u = idx - row * UPR, s = u >> 1, gg = u & 1;
+        const XS sp = split8(a[it], b[it]);
+        const int blk = (((row >> 5) * KS + s) * 2) * 64 + 32 * gg + (row & 31);
+        dst[blk] = sp.hi;
+        dst[blk + 64] = sp.mid;
+      }
+    }
+  }
+};
 
 // ====================================================================================== two-phase staging
 // A kernel prologue that stages its matrices one after the other (load, wait, store to LDS, next

@@ -15,7 +15,7 @@ for path in sys.argv[1:]:
         if hasattr(L, name):
             getattr(L, name).restype, getattr(L, name).argtypes = res, at
     L.gpn_set_precision(1)
-    for N in (196608, 262144):
+    for N in [int(v) for v in os.environ.get('FF_NS', '196608,262144').split(',')]:
         q = torch.randn(N, 64, device=dev); qo = torch.empty_like(q)
         vl = W.view[0]
         fn = lambda: L.gpn_ff(vl.ff_norm_w, vl.ff_norm_b, C.byref(vl.ff1), C.byref(vl.ff2), _lib.ptr(q), N, _lib.ptr(qo), st)
@@ -47,3 +47,13 @@ for path in sys.argv[1:]:
         print("  block start by XCD max:", " ".join("%.1f" % st_.reshape(256, 8).min(axis=1)[k::8].max() for k in range(8)))
         dur = en - st_
         print("  wave duration min/median/max %.2f/%.2f/%.2f us" % (dur.min(), np.median(dur), dur.max()))
+
+    if hasattr(L, "gpn_debug_ffc"):  # k_ff32 region stamps (shader cycles) of waves 0..3 of block 7, second tile
+        buf = (C.c_ulonglong * 128)()
+        L.gpn_debug_ffc(buf)
+        import numpy as np
+        t = np.array(list(buf), dtype=np.int64).reshape(4, 32)
+        for w in range(4):
+            d = t[w, 1:18] - t[w, 0:17]
+            print("  wave %d: y init %d | regions A/B per chunk: %s | tile total %d cycles"
+                  % (w, d[0], " ".join("%d/%d" % (d[1 + 2 * c], d[2 + 2 * c]) for c in range(8)), t[w, 17] - t[w, 0]))

@@ -1346,6 +1346,7 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
   bf8* Ku_s = reinterpret_cast<bf8*>(Ks_s);
   bf8* Vu_s = reinterpret_cast<bf8*>(Vt_s);
   const int sq = 16 * t + j;          // this lane's query / sample index
+  const int jrev = (int)(__builtin_bitreverse32((unsigned)j) >> 28);
   const bool qvalid = sq < S;
   const int sqc = qvalid ? sq : S - 1;
   const float qsel = qvalid ? 1.0f : 0.0f;
@@ -1473,16 +1474,23 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
       const float inv = __builtin_amdgcn_rcpf(sum_over_g(sum));
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) sT[kt] = sT[kt] * f4_splat(inv);
-      // column sums over this wave's queries (for abar) and the query-0 row (for the weights)
+      // column sums over this wave's queries (for abar) and the query-0 row (for the weights).
+      // Padding queries (last tile only) are zeroed in place: their outputs are never stored.
+      if (!all_q) {
 #pragma unroll
-      for (int kt = 0; kt < NT; ++kt) {
+        for (int kt = 0; kt < NT; ++kt) sT[kt] = sT[kt] * f4_splat(qsel);
+      }
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt)
         if (t == 0) wacc[kt] = wacc[kt] + sT[kt];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          // total in lane 15 of each 16-lane row; padding queries (last tile only) are zeroed
-          const float c = row_sum16(all_q ? sT[kt][r] : sT[kt][r] * qsel);
-          if (j == 15) part[((slot * NT + t) * 4 + h) * SP + 16 * kt + 4 * g + r] = c;
-        }
+      for (int grp = 0; grp < (NT + 3) / 4; ++grp) {  // 16 (key tile, register) values per pass, gnt_mfma.h
+        float cv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) cv[e] = 4 * grp + (e >> 2) < NT ? sT[(4 * grp + (e >> 2)) % NT][e & 3] : 0.0f;
+        const float c = row_sums16(cv, j);
+        const int kt = 4 * grp + (jrev >> 2);  // lane j holds the total of value bitrev4(j)
+        if (kt < NT) part[((slot * NT + t) * 4 + h) * SP + 16 * kt + 4 * g + (jrev & 3)] = c;
       }
       // O^T[h] = V_h^T . P^T : A = V (channels of head h on rows), B = P^T (keys in registers)
       f4 o0 = f4_zero(), o1 = f4_zero();

@@ -158,6 +158,27 @@ __device__ __forceinline__ float row_sum16(float v) {
   return v;
 }
 
+// Sums over the 16 lanes of a DPP row of SIXTEEN values at once (recursive halving): at every stage a
+// lane keeps the half of its values its own lane bit selects and adds the partner's partial sums of
+// the same half (partners j^15, j^7, j^3, j^1: row_mirror, row_half_mirror, two quad_perms), so
+// 8 + 4 + 2 + 1 = 15 DPP adds replace the 64 of sixteen row_sum16 calls, and every lane ends up with
+// one total -- lane j with that of v[bitrev4(j)] -- which a single full-wave store can write.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_sums16(const float (&v)[16], int j) {
+  const bool b3 = j & 8, b2 = j & 4, b1 = j & 2, b0 = j & 1;
+  float a[8], b[4], c[2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = (b3 ? v[2 * i + 1] : v[2 * i]) + dpp_f<0x140>(b3 ? v[2 * i] : v[2 * i + 1]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b[i] = (b2 ? a[2 * i + 1] : a[2 * i]) + dpp_f<0x141>(b2 ? a[2 * i] : a[2 * i + 1]);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) c[i] = (b1 ? b[2 * i + 1] : b[2 * i]) + dpp_f<0x1B>(b1 ? b[2 * i] : b[2 * i + 1]);
+  return (b0 ? c[1] : c[0]) + dpp_f<0xB1>(b0 ? c[0] : c[1]);
+}
+
 // LayerNorm over the 64 channels of each point, T-tiles in and out.  gamma/beta are [64] (LDS or
 // global), eps as in the reference (1e-6 inside the transformers, 1e-5 for the final norm).
 __device__ __forceinline__ void layernorm_T(const f4* x, f4* y, const float* gamma,

@@ -1424,54 +1424,78 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
     for (int h = 0; h < 4; ++h) {
       // S^T tile: rows = keys, columns (lanes) = this wave's 16 queries; k-dim = the head's 16 channels
       f4 sT[NT];
-      if constexpr (SPL) {
-        const bf8 qs = split4(qT[h]);
-        bf8 qb1, qb2;
+      auto scores = [&]() {
+        if constexpr (SPL) {
+          const bf8 qs = split4(qT[h]);
+          bf8 qb1, qb2;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          qb1[e] = qs[e], qb1[4 + e] = qs[e];
-          qb2[e] = qs[4 + e], qb2[4 + e] = (__bf16)0.0f;
-        }
-        bf8 ku[NT];
+          for (int e = 0; e < 4; ++e) {
+            qb1[e] = qs[e], qb1[4 + e] = qs[e];
+            qb2[e] = qs[4 + e], qb2[4 + e] = (__bf16)0.0f;
+          }
+          bf8 ku[NT];
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) ku[kt] = Ku_s[(4 * kt + h) * 64 + lane];
+          for (int kt = 0; kt < NT; ++kt) ku[kt] = Ku_s[(4 * kt + h) * 64 + lane];
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) sT[kt] = mfma_bf(ku[kt], qb2, f4_zero());
+          for (int kt = 0; kt < NT; ++kt) sT[kt] = mfma_bf(ku[kt], qb2, f4_zero());
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) sT[kt] = mfma_bf(ku[kt], qb1, sT[kt]);
-      } else {
-        f4 kf[NT];
+          for (int kt = 0; kt < NT; ++kt) sT[kt] = mfma_bf(ku[kt], qb1, sT[kt]);
+        } else {
+          f4 kf[NT];
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-          sT[kt] = f4_zero();
-          kf[kt] = ld4(Ks_s + (16 * kt + j) * LDW + 16 * h + 4 * g);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int kt = 0; kt < NT; ++kt) sT[kt] = mfma16(kf[kt][r], qT[h][r], sT[kt]);
-      }
-      // softmax over keys (registers x the 4 lane groups), scores / sqrt(16)
-      float mx = -INFINITY;
-#pragma unroll
-      for (int kt = 0; kt < NT; ++kt) {
-        if (kt == NT - 1) {  // only the last key tile can hold padding keys
+          for (int kt = 0; kt < NT; ++kt) {
+            sT[kt] = f4_zero();
+            kf[kt] = ld4(Ks_s + (16 * kt + j) * LDW + 16 * h + 4 * g);
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (16 * kt + 4 * g + r >= S) sT[kt][r] = -INFINITY;
-        }
-        mx = max3_nc(mx, max_nc(sT[kt].x, sT[kt].y), max_nc(sT[kt].z, sT[kt].w));
-      }
-      mx = max_over_g(mx);
-      float sum = 0.f;
 #pragma unroll
-      for (int kt = 0; kt < NT; ++kt) {
+            for (int kt = 0; kt < NT; ++kt) sT[kt] = mfma16(kf[kt][r], qT[h][r], sT[kt]);
+        }
+        // only the last key tile can hold padding keys
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          sT[kt][r] = SPL ? __builtin_amdgcn_exp2f(sT[kt][r] - mx) : __expf(sT[kt][r] - mx);
-        sum += (sT[kt].x + sT[kt].y) + (sT[kt].z + sT[kt].w);
+          if (16 * (NT - 1) + 4 * g + r >= S) sT[NT - 1][r] = -INFINITY;
+      };
+      // softmax over keys (registers x the 4 lane groups), scores / sqrt(16); returns the denominator
+      auto softmax_stable = [&]() -> float {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) mx = max3_nc(mx, max_nc(sT[kt].x, sT[kt].y), max_nc(sT[kt].z, sT[kt].w));
+        mx = max_over_g(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            sT[kt][r] = SPL ? __builtin_amdgcn_exp2f(sT[kt][r] - mx) : __expf(sT[kt][r] - mx);
+          sum += (sT[kt].x + sT[kt].y) + (sT[kt].z + sT[kt].w);
+        }
+        return sum_over_g(sum);
+      };
+      scores();
+      float tot;
+      if constexpr (SPL) {
+        // Softmax is shift invariant and the scores of LayerNorm'ed rows are small: take the bare
+        // exponentials (no running maximum: 16 NT compare / subtract pairs and two cross-lane maxima
+        // fewer per head) and fall back to the shifted form when a denominator leaves the safe range.
+        // One wave = queries of ONE ray, so a ray's result does not depend on its workgroup mates.
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sT[kt][r] = __builtin_amdgcn_exp2f(sT[kt][r]);
+          sum += (sT[kt].x + sT[kt].y) + (sT[kt].z + sT[kt].w);
+        }
+        tot = sum_over_g(sum);
+        if (__builtin_expect(__any(!(tot > 1e-30f && tot < 1e30f)), 0)) {
+          scores();
+          tot = softmax_stable();
+        }
+      } else {
+        tot = softmax_stable();
       }
-      const float inv = __builtin_amdgcn_rcpf(sum_over_g(sum));
+      const float inv = __builtin_amdgcn_rcpf(tot);
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) sT[kt] = sT[kt] * f4_splat(inv);
       // column sums over this wave's queries (for abar) and the query-0 row (for the weights).

@@ -406,6 +406,42 @@ def test_gnt_stages(dev, net, prec, S):
     assert not bad, "stage errors above %g: %s (all: %s)" % (STAGE_TOL[prec], bad, errs)
 
 
+def test_ray_attn_large_scores(dev, prec):
+    """gpn_ray_attn takes bare exponentials in bf16x3 mode (no running maximum) and falls back to the
+    shifted softmax when a denominator leaves the safe range.  q_fc / k_fc scaled 17x put the scores at
+    ~+-100 (2^144 overflows fp32), so this case runs the fallback; S = 40 also has padding keys.
+    Tolerance: a score of 100 carries 100 * 2^-16 of split-operand error, i.e. ~4e-4 on an attention
+    weight (fp32 mode: 100 * 2^-23)."""
+    from gp_nerf_amd import _lib
+    from gp_nerf_amd.transformer_network import GNT
+    sd = {k: v.clone() for k, v in cases.weights().items()}
+    for n in ("q_fc", "k_fc"):
+        sd["view_selftrans.0.attn.%s.weight" % n] *= 17.0
+    args = types.SimpleNamespace(netwidth=64, trans_depth=8, save_feature=False,
+                                 semantic_model="fpn", num_classes=20)
+    big = GNT(args, in_feat_ch=32, posenc_dim=63, viewenc_dim=63, ret_alpha=True)
+    big.load_state_dict(sd, strict=True)
+    big = big.to(dev).eval()
+    big.precision = prec
+    W = big._weights()
+    L, st = _lib.lib(), _lib.stream()
+    R, S = 37, 40
+    x = torch.randn(R, S, 64, generator=torch.Generator().manual_seed(11)) * 1.5
+    _, A, mid = oracle.gnt.ray_transformer(sd, "view_selftrans.0", x)
+    scores_max = float((torch.log(A.max(dim=-1)[0]) - torch.log(A.min(dim=-1)[0])).max())
+    assert scores_max > 100.0, "the case does not reach the overflow range (%g)" % scores_max
+    xd = x.to(dev).contiguous()
+    xo, ab, wt = torch.empty(R, S, 64, device=dev), torch.empty(R, S, 4, device=dev), torch.empty(R, S, device=dev)
+    _lib.check(L.gpn_ray_attn(C.byref(W.ray[0]), _lib.ptr(xd), R, S, _lib.ptr(xo), _lib.ptr(ab), 4,
+                              _lib.ptr(wt), st), "ray-large")
+    torch.cuda.synchronize()
+    tol = 5e-3 if prec == "bf16x3" else 1e-4
+    errs = {"x": rel(xo, mid), "abar": rel(ab, A.mean(dim=2).permute(0, 2, 1)),
+            "weights": rel(wt, A.mean(dim=1)[:, 0])}
+    print("large-score ray attention [%s]: %s" % (prec, errs))
+    assert max(errs.values()) < tol, errs
+
+
 def test_gnt_stages_many_tiles(dev, net, prec):
     """The per-point kernels are persistent: a wave walks several tiles and fetches the next tile's
     inputs ahead.  The golden cases are smaller than one tile per wave, so this case (70,400 points,

@@ -1839,26 +1839,48 @@ k_heads_rgb(const float* __restrict__ norm_w, const float* __restrict__ norm_b, 
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= R) return;
-  // lane l owns channel l; each sample's 64 channels are normalised with a wave reduction
-  const float ga = norm_w[lane], be = norm_b[lane];
-  float hsum = 0.f, dsum = 0.f;
-  for (int s = 0; s < S; ++s) {
-    const float x = q[((size_t)r * S + s) * C64 + lane];
-    float m = x;
-    for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o);
-    m *= (1.0f / 64.0f);
-    const float d = x - m;
-    float vv = d * d;
-    for (int o = 32; o > 0; o >>= 1) vv += __shfl_xor(vv, o);
-    vv *= (1.0f / 64.0f);
-    hsum += d * (1.0f / sqrtf(vv + 1e-5f)) * ga + be;
+  // One wave per ray, four samples at a time: the 16 lanes of a DPP row own one sample's 64 channels
+  // (lane (g, j): sample s0 + g, channels 4j..4j+3, one 16-byte load); the per-sample LayerNorm
+  // statistics are xor-butterflies inside the row (every lane gets the total), independent across
+  // the unrolled iterations.
+  const int j = lane & 15, g = lane >> 4;
+  const f4 ga = ld4(norm_w + 4 * j), be = ld4(norm_b + 4 * j);
+  auto row_all = [](float v) {  // sum over the 16 lanes of the row, result in every lane
+    v += dpp_f<0xB1>(v);   // ^1
+    v += dpp_f<0x4E>(v);   // ^2
+    v += dpp_f<0x141>(v);  // row_half_mirror: the other quad of the half
+    v += dpp_f<0x140>(v);  // row_mirror: the other half
+    return v;
+  };
+  f4 hsum = f4_zero();
+  for (int s0 = 0; s0 < S; s0 += 16) {  // 4 x 4 samples per trip: four independent loads / butterflies
+    f4 x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int s = s0 + 4 * u + g;
+      x[u] = ld4(q + ((size_t)r * S + (s < S ? s : S - 1)) * C64 + 4 * j);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool ok = s0 + 4 * u + g < S;
+      const float m = row_all((x[u].x + x[u].y) + (x[u].z + x[u].w)) * (1.0f / 64.0f);
+      const f4 d = x[u] - f4_splat(m);
+      const float vv = row_all((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.0f / 64.0f);
+      const float rstd = ok ? 1.0f / sqrtf(vv + 1e-5f) : 0.0f;
+      const f4 t = d * f4_splat(rstd) * ga + be;
+      if (ok) hsum = hsum + t;
+    }
   }
-  const float hmean = hsum / (float)S;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) hsum[e] = sum_over_g(hsum[e]);  // the four sample groups
+  const f4 hmean = hsum / f4_splat((float)S);
+#pragma unroll
   for (int c = 0; c < 3; ++c) {
-    float p = rgb_fc.w[c * C64 + lane] * hmean;
-    for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
+    const f4 w = ld4(rgb_fc.w + c * C64 + 4 * j);
+    const float p = row_all((w.x * hmean.x + w.y * hmean.y) + (w.z * hmean.z + w.w * hmean.w));
     if (lane == 0) out[(size_t)r * (3 + S) + c] = p + (rgb_fc.b ? rgb_fc.b[c] : 0.f);
   }
+  float dsum = 0.f;
   for (int s = lane; s < S; s += 64) {
     const float w = weights[(size_t)r * S + s];
     out[(size_t)r * (3 + S) + 3 + s] = w;
@@ -2184,6 +2206,8 @@ extern "C" int gpn_heads(const gpn_gnt_weights_t* W, const float* q, const float
   GPN_REQUIRE(W && q && weights && out, "gpn_heads: null pointer");
   GPN_REQUIRE(W->norm_w && W->norm_b && W->rgb_fc.w, "gpn_heads: null weight");
   GPN_REQUIRE(R >= 0 && S >= 1, "gpn_heads: bad shape");
+  GPN_REQUIRE(aligned16(q) && aligned16(W->norm_w) && aligned16(W->norm_b) && aligned16(W->rgb_fc.w),
+              "gpn_heads: q and the norm / rgb_fc weights must be 16-byte aligned");
   if (R == 0) return GPN_OK;
   {
     GpnStageTimer timer_k_heads_rgb_(GPN_ST_HEADS, (hipStream_t)stream);

@@ -1893,7 +1893,7 @@ k_heads_rgb(const float* __restrict__ norm_w, const float* __restrict__ norm_b, 
 }
 
 // sem_feat = ReLU(W pre + b): [R,512] x [512,512]^T on MFMA; one wave per (16 rays, 128 outputs).
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 k_sem_adaptor(gpn_linear_t fc, const float* __restrict__ pre, int R, float* __restrict__ sem_feat) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
@@ -1905,7 +1905,8 @@ k_sem_adaptor(gpn_linear_t fc, const float* __restrict__ pre, int R, float* __re
 #pragma unroll
   for (int T = 0; T < 32; ++T) x[T] = ld4(pre + (size_t)rc * GPN_SEM + 16 * T + 4 * g);
   const float* wp = fc.w + (size_t)j * GPN_SEM + 4 * g;
-  for (int M0 = wave * 8; M0 < wave * 8 + 8; M0 += 4) {
+  {  // 8 waves x 64 output columns: two waves per SIMD hide the L2 latency of the weight reads
+    const int M0 = wave * 4;
     f4 y[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -2220,7 +2221,7 @@ extern "C" int gpn_heads(const gpn_gnt_weights_t* W, const float* q, const float
     REQ_LIN(W->sem_adaptor, "gpn_heads.sem_adaptor");
     GPN_REQUIRE(aligned16(pre) && aligned16(sem_feat), "gpn_heads: sem tensors must be aligned");
     GpnStageTimer timer_k_sem_adaptor_(GPN_ST_HEADS, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_sem_adaptor, dim3(gpn_ceil_div(R, 16)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_sem_adaptor, dim3(gpn_ceil_div(R, 16)), dim3(512), 0, (hipStream_t)stream,
                        W->sem_adaptor, pre, R, sem_feat);
     GPN_LAUNCH_CHECK("k_sem_adaptor");
   }

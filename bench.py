@@ -195,11 +195,11 @@ def main():
     tile_w = 2 * (3 + 1 + 512)
     gathered = torch.empty((world * CHUNK, tile_w), device=dev) if world > 1 else None
 
-    def step():
+    def step(collective=True):
         ret = render_rays(rb, model, scene.featmaps, scene.deep, projector, N_samples=N_SAMPLES,
                           inv_uniform=True, N_importance=N_IMPORTANCE, det=True, ret_alpha=True,
                           single_net=True)
-        if world > 1:  # rgb / depth / semantic tiles of both levels, one collective
+        if world > 1 and collective:  # rgb / depth / semantic tiles of both levels, one collective
             c, f = ret["outputs_coarse"], ret["outputs_fine"]
             tile = torch.cat([c["rgb"], c["depth"][:, None], c["feats_out"],
                               f["rgb"], f["depth"][:, None], f["feats_out"]], dim=1)
@@ -233,9 +233,9 @@ def main():
     ret, elapsed, tm = timed(a.precision, a.steps, a.warmup)
 
     # dominant kernel: k_view_attn, 8 launches on N=4096*48 points + 8 on N=4096*64 per step.
-    # It is HBM-bound (62 % of the 8 TB/s peak in measured traffic, at the
+    # It is HBM-bound (51 % of the 8 TB/s peak in measured traffic, 86 % of the
     # ceiling a bare copy kernel reaches for the same access shape -- random 256-byte rows read and
-    # written -- while the MFMA pipe is < 20 % busy), so the roofline is the HBM one:
+    # written; its time follows its bytes, not its instruction count), so the roofline is the HBM one:
     # achieved = ALGORITHMIC bytes per launch / mean launch time.
     launches = tm.launches["view_attn"]
     mean_ms = tm.ms["view_attn"] / max(1, launches)
@@ -281,7 +281,7 @@ def main():
     stages = None
     if a.breakdown or rank == 0:
         with _lib.stage_timing() as tb:  # one extra, untimed step with every stage instrumented
-            step()
+            step(collective=False)  # rank-local: not every rank runs this block
             torch.cuda.synchronize()
         stages = {k: round(v, 4) for k, v in tb.ms.items() if tb.launches[k]}
         if a.breakdown and rank == 0:

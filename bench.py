@@ -180,10 +180,20 @@ def main():
                      "GPU); WORLD_SIZE is 1" % a.gpus)
         a.gpus = world
     import torch.distributed as dist
+    # rehearsal aid for a one-GPU box (tools/rehearse_ranks.sh): every rank on cuda:0 over gloo -- RCCL
+    # refuses two ranks on one device.  Never set by the driver; numbers from such a run mean nothing.
+    rehearse = os.environ.get("GPN_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = 0
+        import faulthandler
+        faulthandler.dump_traceback_later(240, exit=True)  # a hang names its line
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from gp_nerf_amd import _lib
     from gp_nerf_amd.render_ray import render_rays

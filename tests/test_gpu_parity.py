@@ -92,6 +92,11 @@ def rel(a, b):
     return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
 
 
+def _lib_reset_precision():
+    from gp_nerf_amd import _lib
+    _lib.set_precision("fp32")
+
+
 def to(dev, d):
     return {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in d.items()}
 
@@ -660,6 +665,51 @@ def test_render_rays_stress_shape(dev, net, prec):
 
 
 # ------------------------------------------------------------------------------ ray generation (8(f) rank 1)
+def test_full_size_properties(dev):
+    """BASELINE.json configs[1] at full size (4096 rays, 48 + 16 samples, 10 views, 640x480 maps: too big
+    for the CPU oracle in a test) through size-independent properties of the path:
+    * chunk invariance: the 4096-ray chunk equals its two ragged halves rendered separately, bit for bit
+      (reference render_image.py:39-62 relies on rays being independent);
+    * every attention-weight row is a distribution (sums to 1), everything finite;
+    * linearity in the deep-semantic maps: doubling the maps doubles feats_out_3d
+      exactly and leaves rgb / weights / depth untouched bit for bit."""
+    import bench
+    from gp_nerf_amd.render_ray import render_rays
+    scene, gnt, projector = bench.build(dev)
+    gnt.precision = "bf16x3"
+    model = types.SimpleNamespace(net_coarse=gnt, net_fine=None)
+    rb = bench.ray_chunk(scene, 0, 1, dev)
+
+    def run(batch, deep):
+        return render_rays(batch, model, scene.featmaps, deep, projector, N_samples=48, inv_uniform=True,
+                           N_importance=16, det=True, ret_alpha=True, single_net=True)
+
+    def part(lo, hi):
+        b = dict(rb)
+        b["ray_o"], b["ray_d"] = rb["ray_o"][lo:hi].contiguous(), rb["ray_d"][lo:hi].contiguous()
+        return b
+
+    full = run(rb, scene.deep)
+    R = rb["ray_o"].shape[0]
+    assert R == 4096
+    halves = [run(part(0, 1500), scene.deep), run(part(1500, R), scene.deep)]
+    for lvl, S in (("outputs_coarse", 48), ("outputs_fine", 64)):
+        for k in ("rgb", "depth", "weights", "feats_out", "feats_out_3d"):
+            whole = full[lvl][k]
+            joined = torch.cat([h[lvl][k] for h in halves], dim=0)
+            assert torch.equal(whole.view(torch.int32), joined.view(torch.int32)), (lvl, k)
+            assert bool(torch.isfinite(whole).all()), (lvl, k)
+        assert full[lvl]["weights"].shape == (R, S)
+        assert float((full[lvl]["weights"].sum(-1) - 1.0).abs().max()) < 1e-5
+        assert bool((full[lvl]["weights"] >= 0).all())
+    twice = run(rb, (scene.deep * 2.0).contiguous())
+    for lvl in ("outputs_coarse", "outputs_fine"):
+        for k in ("rgb", "depth", "weights"):
+            assert torch.equal(twice[lvl][k].view(torch.int32), full[lvl][k].view(torch.int32)), (lvl, k)
+        assert torch.equal(twice[lvl]["feats_out_3d"], full[lvl]["feats_out_3d"] * 2.0), lvl
+    _lib_reset_precision()
+
+
 def test_ray_sampler_bit_exact(dev, golden):
     """RaySamplerSingleImage on the device vs the reference's own sampler (golden g6): rays_o / rays_d
     bit-exact, get_all() / random_sample() dictionaries as in reference sample_ray.py:134-214."""

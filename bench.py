@@ -186,7 +186,7 @@ def main():
     if rehearse:
         local = 0
         import faulthandler
-        faulthandler.dump_traceback_later(240, exit=True)  # a hang names its line
+        faulthandler.dump_traceback_later(150, exit=True)  # a hang names its line
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -213,7 +213,12 @@ def main():
             c, f = ret["outputs_coarse"], ret["outputs_fine"]
             tile = torch.cat([c["rgb"], c["depth"][:, None], c["feats_out"],
                               f["rgb"], f["depth"][:, None], f["feats_out"]], dim=1)
-            dist.all_gather_into_tensor(gathered, tile)
+            if rehearse:  # gloo stages device tensors through the host unreliably: gather host copies
+                host = torch.empty((world * CHUNK, tile_w))
+                dist.all_gather_into_tensor(host, tile.cpu())
+                gathered.copy_(host)
+            else:
+                dist.all_gather_into_tensor(gathered, tile)
         return ret
 
     def fence():

@@ -929,6 +929,18 @@ k_ff(const float* __restrict__ norm_w, const float* __restrict__ norm_b, gpn_lin
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   STAMP(8);
   WAVE_T(0);
+  // split mode: the first input tiles are requested before the weights (their HBM latency then
+  // runs under the staging instead of after the barrier)
+  [[maybe_unused]] f4 xpre[FF_NTL][4];
+  if constexpr (SPL) {
+    const long long pr0 = (long long)blockIdx.x * (FF_TPB / 64) + wave;
+#pragma unroll
+    for (int t = 0; t < FF_NTL; ++t) {
+      const long long np = (pr0 * FF_NTL + t) * 16 + (lane & 15), npc = np < N ? np : N - 1;
+#pragma unroll
+      for (int T = 0; T < 4; ++T) xpre[t][T] = ld4(x_in + (size_t)npc * C64 + 16 * T + 4 * (lane >> 4));
+    }
+  }
   {  // two-phase staging (gnt_mfma.h): every global load first, then the LDS images
     WStage<SPL, 256, 4, FF_TPB> s1;
     WStage<SPL, 64, 16, FF_TPB> s2;
@@ -953,14 +965,7 @@ k_ff(const float* __restrict__ norm_w, const float* __restrict__ norm_b, gpn_lin
     const long long ngroups = (ntiles + NTL - 1) / NTL;
     const long long stride = (long long)gridDim.x * (FF_TPB / 64);
     long long pr = (long long)blockIdx.x * (FF_TPB / 64) + wave;
-    // the input tiles of the next iteration are loaded one iteration ahead
-    f4 xpre[NTL][4];
-#pragma unroll
-    for (int t = 0; t < NTL; ++t) {
-      const long long np = (pr * NTL + t) * 16 + j, npc = np < N ? np : N - 1;
-#pragma unroll
-      for (int T = 0; T < 4; ++T) xpre[t][T] = ld4(x_in + (size_t)npc * C64 + 16 * T + 4 * g);
-    }
+    // the input tiles of the next iteration are loaded one iteration ahead (the first ones: above)
     for (; pr < ngroups; pr += stride) {
       long long n[NTL];
       XS xs[NTL][2];
@@ -1329,16 +1334,6 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
   float* Vt = Ks + RPW * SP * LDW;
   float* part = Vt + RPW * 64 * LDV;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  {  // two-phase staging (gnt_mfma.h): every global load first, then the LDS images
-    WStage<SPL, 64, 4, NTHR> sq, sk, sv, so;
-    VecStage<64, NTHR> vo, vg, vb;
-    sq.load(Lw.q.w, 64, 64, tid), sk.load(Lw.k.w, 64, 64, tid), sv.load(Lw.v.w, 64, 64, tid);
-    so.load(Lw.out.w, 64, 64, tid);
-    vo.load(Lw.out.b, 64, tid), vg.load(Lw.attn_norm_w, 64, tid), vb.load(Lw.attn_norm_b, 64, tid);
-    sq.store(Wq, LDW, tid), sk.store(Wk, LDW, tid), sv.store(Wv, LDW, tid), so.store(Wo, LDW, tid);
-    vo.store(bO, tid), vg.store(gam, tid), vb.store(bet, tid);
-  }
-  __syncthreads();
   const int j = lane & 15, g = lane >> 4;
   const int slot = wave / NT, t = wave - slot * NT;
   float* Ks_s = Ks + slot * SP * LDW;
@@ -1351,13 +1346,25 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
   const int sqc = qvalid ? sq : S - 1;
   const float qsel = qvalid ? 1.0f : 0.0f;
 
-  f4 xpre[4];  // next iteration's input tile, loaded one iteration ahead
+  // next iteration's input tile, loaded one iteration ahead; the first one is requested before the
+  // weights, so that its HBM latency runs under the staging
+  f4 xpre[4];
   {
     const int r0 = blockIdx.x * RPW + slot;
     const size_t row0 = ((size_t)(r0 < R ? r0 : R - 1) * S + sqc) * C64;
 #pragma unroll
     for (int T = 0; T < 4; ++T) xpre[T] = ld4(x_in + row0 + 16 * T + 4 * g);
   }
+  {  // two-phase staging (gnt_mfma.h): every global load first, then the LDS images
+    WStage<SPL, 64, 4, NTHR> sq, sk, sv, so;
+    VecStage<64, NTHR> vo, vg, vb;
+    sq.load(Lw.q.w, 64, 64, tid), sk.load(Lw.k.w, 64, 64, tid), sv.load(Lw.v.w, 64, 64, tid);
+    so.load(Lw.out.w, 64, 64, tid);
+    vo.load(Lw.out.b, 64, tid), vg.load(Lw.attn_norm_w, 64, tid), vb.load(Lw.attn_norm_b, 64, tid);
+    sq.store(Wq, LDW, tid), sk.store(Wk, LDW, tid), sv.store(Wv, LDW, tid), so.store(Wo, LDW, tid);
+    vo.store(bO, tid), vg.store(gam, tid), vb.store(bet, tid);
+  }
+  __syncthreads();
   for (int grp = blockIdx.x; grp * RPW < R; grp += gridDim.x) {
     const int ray = grp * RPW + slot;
     const bool valid = ray < R;

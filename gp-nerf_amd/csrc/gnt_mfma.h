@@ -33,33 +33,25 @@ __device__ __forceinline__ f4 f4_splat(float v) { return (f4){v, v, v, v}; }
 __device__ __forceinline__ float max_nc(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
 __device__ __forceinline__ float max3_nc(float a, float b, float c) { return max_nc(max_nc(a, b), c); }
 // max(x, 0): fmaxf / fmed3 make hipcc put a canonicalising v_max_f32 x, x in front of the real one
-// (256 of the 921 vector instructions of a split-mode k_ff iteration were those pairs).
-// f4_relu_t<true> is the single-instruction form; its result must be consumed by a VECTOR instruction (the
-// operand split of the bf16x3 mode): hipcc does not insert the wait states an MFMA reading a
-// register written inside an asm statement needs.  relu1 is the safe form for MFMA consumers.
+// (256 of the 921 vector instructions of a split-mode k_ff iteration were those pairs); relu1 keeps
+// that exact-fp32 form (NaN-propagating like the reference), relu_i below is the one-instruction form.
 __device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
 __device__ __forceinline__ f4 f4_relu(f4 v) { return (f4){relu1(v.x), relu1(v.y), relu1(v.z), relu1(v.w)}; }
-// VALU_CONSUMER = the result feeds the bf16x3 operand split (never an MFMA directly)
-template <bool VALU_CONSUMER>
-__device__ __forceinline__ f4 f4_relu_t(f4 v) {
-  if constexpr (VALU_CONSUMER) {
-    // in place, one statement per f4; the leading s_nop covers a store still reading these registers
-    // (hipcc's hazard handling does not look inside asm statements)
-    asm("s_nop 1\n\tv_max_f32 %0, 0, %0\n\tv_max_f32 %1, 0, %1\n\tv_max_f32 %2, 0, %2\n\tv_max_f32 %3, 0, %3"
-        : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
-    return v;
-  } else {
-    return f4_relu(v);
-  }
-}
 // max(x, 0) on the bit pattern: a negative float is a negative int, so one v_max_i32 does it -- no
-// canonicalising pre-pass, and a compiler-visible instruction (hipcc inserts the wait states a read of
-// an MFMA result needs; it does not for the asm form above)
+// canonicalising pre-pass, and a compiler-visible instruction: hipcc inserts the wait states a read of
+// an MFMA result needs (an earlier inline-asm v_max_f32 form did not get them: wrong values when the
+// ReLU directly followed the MFMA that produced its input).
 __device__ __forceinline__ float relu_i(float x) {
   const int v = __builtin_bit_cast(int, x);
   return __builtin_bit_cast(float, v > 0 ? v : 0);
 }
 __device__ __forceinline__ f4 f4_relu_i(f4 v) { return (f4){relu_i(v.x), relu_i(v.y), relu_i(v.z), relu_i(v.w)}; }
+// VALU_CONSUMER = the result feeds the bf16x3 operand split: the single-instruction integer form
+template <bool VALU_CONSUMER>
+__device__ __forceinline__ f4 f4_relu_t(f4 v) {
+  if constexpr (VALU_CONSUMER) return f4_relu_i(v);
+  else return f4_relu(v);
+}
 __device__ __forceinline__ f4 f4_max(f4 a, f4 b) {
   return (f4){max_nc(a.x, b.x), max_nc(a.y, b.y), max_nc(a.z, b.z), max_nc(a.w, b.w)};
 }

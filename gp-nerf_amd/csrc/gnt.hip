@@ -439,54 +439,10 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (tile loop, LDS-DMA base)
   STAMP(0);
   static_assert(SPL || !FOLD, "the folded algorithm exists in split mode only");
-  {  // two-phase staging (gnt_mfma.h): every global load first, then the LDS images
-    WStage<SPL, 64, 4, VA_TPB> sq, sk, sv, so;
-    WStage<SPL, 16, 6, VA_TPB> saf;
-    WStage<SPL, 64, 1, VA_TPB> sp2, sa2;
-    WStage<SPL, 16, 4, VA_TPB> sa0;
-    RowStage<16, 1, VA_TPB> sp0;
-    VecStage<16, VA_TPB> vc0, vbp0, vba0;
-    VecStage<64, VA_TPB> vbp2, vba2, vbo, vga, vbe;
-    sq.load(Lw.q.w, 64, 64, tid);
-    if constexpr (FOLD) {  // Wv slot holds Wv Wk; k itself is never formed
-      sv.load(Lw.folded + FOLD_VK, 64, 64, tid);
-      saf.load(Lw.folded + FOLD_AF, 16, 96, tid);
-      vc0.load(Lw.folded + FOLD_C0, 16, tid);
-    } else {
-      sk.load(Lw.k.w, 64, 64, tid);
-      sv.load(Lw.v.w, 64, 64, tid);
-    }
-    so.load(Lw.out.w, 64, 64, tid);
-    sp2.load(Lw.pos2.w, 64, 8, tid);
-    sa0.load(Lw.attn0.w, 8, 64, tid);
-    sa2.load(Lw.attn2.w, 64, 8, tid);
-    sp0.load(Lw.pos0.w, 8, 4, tid);
-    vbp0.load(Lw.pos0.b, 8, tid), vbp2.load(Lw.pos2.b, 64, tid), vba0.load(Lw.attn0.b, 8, tid);
-    vba2.load(Lw.attn2.b, 64, tid), vbo.load(Lw.out.b, 64, tid);
-    vga.load(Lw.attn_norm_w, 64, tid), vbe.load(Lw.attn_norm_b, 64, tid);
-    sq.store(L.Wq, LDW, tid);
-    if constexpr (FOLD) {
-      sv.store(L.Wv, LDW, tid);
-      saf.store(L.AF, 0, tid);
-      vc0.store(L.c0, tid);
-    } else {
-      sk.store(L.Wk, LDW, tid);
-      sv.store(L.Wv, LDW, tid);
-    }
-    so.store(L.Wo, LDW, tid);
-    sp2.store(L.P2, VA_LD8, tid);
-    sa0.store(L.A0, LDW, tid);
-    sa2.store(L.A2, VA_LD8, tid);
-    sp0.store(L.P0, 4, tid);
-    vbp0.store(L.bP0, tid), vbp2.store(L.bP2, tid), vba0.store(L.bA0, tid), vba2.store(L.bA2, tid);
-    STAMP(1);
-    vbo.store(L.bO, tid), vga.store(L.gam, tid), vbe.store(L.bet, tid);
-  }
-  __syncthreads();
-
-  STAMP(2);
+  // Everything the first tile needs from global memory is requested BEFORE / WHILE the weights are
+  // staged: slot -> point lookups first, then the weight loads, then the first two ring fills and
+  // the q rows; their latencies run under the LDS stores and the barrier instead of after it.
   const int j = lane & 15, g = lane >> 4;
-  const float p0w = L.P0[j * 4 + g];  // A operand of the 4 -> 8 layer: W[i = j][k = g]
   const long long ntiles = (N + 15) >> 4;
   const long long tstride = (long long)gridDim.x * (VA_TPB / 64);
   const unsigned all_views = V >= 32 ? 0xffffffffu : ((1u << V) - 1u);
@@ -587,11 +543,11 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
   };
 
   long long tile = (long long)blockIdx.x * (VA_TPB / 64) + wave;
-  if (tile >= ntiles) return;
+  const bool has_tile = tile < ntiles;  // (a wave without a tile still takes part in the staging)
   // points and visibility of the current tile and of the next two; the third one ahead is in flight
-  int n, n1, n2, n3;  // N fits an int (C-ABI)
-  unsigned vis, vis1, vis2, vis3;
-  point_of(tile, n, vis);
+  int n = 0, n1, n2, n3;  // N fits an int (C-ABI)
+  unsigned vis = 0, vis1, vis2, vis3;
+  if (has_tile) point_of(tile, n, vis);
   n1 = n2 = n3 = n;
   vis1 = vis2 = vis3 = vis;
   if (tile + tstride < ntiles) point_of(tile + tstride, n1, vis1);
@@ -628,11 +584,60 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
     else if (live1) dma_pair(n1, __builtin_ctz(live1), 1);
     else dma_pair(n, v0, 1);  // no further pair: keep the op count
   };
-  ring_start();
-
   f4 xq[4];
+  {  // two-phase staging (gnt_mfma.h): every global load first, then the LDS images
+    WStage<SPL, 64, 4, VA_TPB> sq, sk, sv, so;
+    WStage<SPL, 16, 6, VA_TPB> saf;
+    WStage<SPL, 64, 1, VA_TPB> sp2, sa2;
+    WStage<SPL, 16, 4, VA_TPB> sa0;
+    RowStage<16, 1, VA_TPB> sp0;
+    VecStage<16, VA_TPB> vc0, vbp0, vba0;
+    VecStage<64, VA_TPB> vbp2, vba2, vbo, vga, vbe;
+    sq.load(Lw.q.w, 64, 64, tid);
+    if constexpr (FOLD) {  // Wv slot holds Wv Wk; k itself is never formed
+      sv.load(Lw.folded + FOLD_VK, 64, 64, tid);
+      saf.load(Lw.folded + FOLD_AF, 16, 96, tid);
+      vc0.load(Lw.folded + FOLD_C0, 16, tid);
+    } else {
+      sk.load(Lw.k.w, 64, 64, tid);
+      sv.load(Lw.v.w, 64, 64, tid);
+    }
+    so.load(Lw.out.w, 64, 64, tid);
+    sp2.load(Lw.pos2.w, 64, 8, tid);
+    sa0.load(Lw.attn0.w, 8, 64, tid);
+    sa2.load(Lw.attn2.w, 64, 8, tid);
+    sp0.load(Lw.pos0.w, 8, 4, tid);
+    vbp0.load(Lw.pos0.b, 8, tid), vbp2.load(Lw.pos2.b, 64, tid), vba0.load(Lw.attn0.b, 8, tid);
+    vba2.load(Lw.attn2.b, 64, tid), vbo.load(Lw.out.b, 64, tid);
+    vga.load(Lw.attn_norm_w, 64, tid), vbe.load(Lw.attn_norm_b, 64, tid);
+    if (has_tile) {
+      ring_start();
 #pragma unroll
-  for (int T = 0; T < 4; ++T) xq[T] = ld4(q_in + (size_t)n * C64 + 16 * T + 4 * g);
+      for (int T = 0; T < 4; ++T) xq[T] = ld4(q_in + (size_t)n * C64 + 16 * T + 4 * g);
+    }
+    sq.store(L.Wq, LDW, tid);
+    if constexpr (FOLD) {
+      sv.store(L.Wv, LDW, tid);
+      saf.store(L.AF, 0, tid);
+      vc0.store(L.c0, tid);
+    } else {
+      sk.store(L.Wk, LDW, tid);
+      sv.store(L.Wv, LDW, tid);
+    }
+    so.store(L.Wo, LDW, tid);
+    sp2.store(L.P2, VA_LD8, tid);
+    sa0.store(L.A0, LDW, tid);
+    sa2.store(L.A2, VA_LD8, tid);
+    sp0.store(L.P0, 4, tid);
+    vbp0.store(L.bP0, tid), vbp2.store(L.bP2, tid), vba0.store(L.bA0, tid), vba2.store(L.bA2, tid);
+    STAMP(1);
+    vbo.store(L.bO, tid), vga.store(L.gam, tid), vbe.store(L.bet, tid);
+  }
+  __syncthreads();
+
+  STAMP(2);
+  if (!has_tile) return;
+  const float p0w = L.P0[j * 4 + g];  // A operand of the 4 -> 8 layer: W[i = j][k = g]
 
   unsigned long long redo_lanes = 0;  // lanes (points) of the current tile to redo in the online form
   // a point = the 4 lanes (j, g = 0..3): all of them redo if any of their channels overflowed

@@ -411,6 +411,31 @@ def test_gnt_stages(dev, net, prec, S):
     assert not bad, "stage errors above %g: %s (all: %s)" % (STAGE_TOL[prec], bad, errs)
 
 
+@pytest.mark.parametrize("scale", [1.0, 40.0, 400.0])
+def test_posenc_argument_ranges(dev, scale):
+    """gpn_posenc's sin / cos: Cody-Waite reduction + polynomial kernels for |arg| <= 1e5, libm's
+    sincosf beyond.  Coordinates scaled so that the top frequency (2^9) reaches ~4e3 (a room), ~1.6e5
+    (both branches in one launch) and ~1.6e6 (libm only); reference transformer_network.py:6-37.
+    Bound: 2e-7 absolute against the fp32 oracle (one ulp of a value near 1 is 6e-8 on each side)."""
+    from gp_nerf_amd import _lib
+    L, st = _lib.lib(), _lib.stream()
+    g = torch.Generator().manual_seed(17)
+    R, S = 64, 48
+    pts = (torch.rand(R, S, 3, generator=g) * 16.0 - 8.0) * scale
+    ray_d = torch.randn(R, 3, generator=g)
+    want, _ = oracle.gnt.encodings(pts, ray_d)
+    pd, rd = pts.to(dev).contiguous(), ray_d.to(dev).contiguous()
+    emb_pt, emb_ray = torch.empty(R * S, 64, device=dev), torch.empty(R, 64, device=dev)
+    _lib.check(L.gpn_posenc(_lib.ptr(pd), _lib.ptr(rd), R, S, _lib.ptr(emb_pt), _lib.ptr(emb_ray), st), "posenc")
+    torch.cuda.synchronize()
+    got = emb_pt[:, :63].cpu().reshape(R, S, 63)
+    assert bool(torch.isfinite(got).all())
+    assert torch.equal(got[..., :3], pts), "the identity columns are copies"
+    err = float((got[..., 3:] - want[..., 3:]).abs().max())
+    print("posenc scale %g: max |arg| %.3g, max abs error %.3g" % (scale, float(pts.abs().max()) * 512, err))
+    assert err < 2e-7, err
+
+
 def test_ray_attn_large_scores(dev, prec):
     """gpn_ray_attn takes bare exponentials in bf16x3 mode (no running maximum) and falls back to the
     shifted softmax when a denominator leaves the safe range.  q_fc / k_fc scaled 17x put the scores at

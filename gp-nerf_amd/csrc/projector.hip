@@ -31,68 +31,65 @@ __global__ void k_repack_nhwc(const float* __restrict__ src, float* __restrict__
 }
 
 // ---------------------------------------------------------------- RGB + feature gather, mask, ray_diff
-// 256 threads = 32 (point,view) pairs x 8 lanes; lane q of a pair owns feature channels 4q..4q+3.
-constexpr int PAIRS = 32;
+// 256 threads work on 256 (point, view) pairs at a time, in two phases:
+//   1. one LANE per pair does the per-pair arithmetic once -- projection, in-front / in-bounds mask,
+//      the tap positions and bilinear weights on both maps (8 correctly rounded divisions), ray_diff
+//      (9 divisions, 3 square roots) -- writes mask / ray_diff / the optional geometry outputs
+//      (consecutive lanes, consecutive addresses) and leaves the taps in LDS;
+//   2. 8 lanes per pair gather: lane q owns feature channels 4q..4q+3 (one float4 per tap), lanes 0-2
+//      one RGB channel each; rows go through LDS and leave as one contiguous, coalesced span.
+// (With 8 lanes per pair doing phase 1 as well -- the first form of this kernel -- every wave ran the
+// whole per-pair arithmetic for 8 pairs only: it was instruction-bound at 2.7 TB/s.)
+constexpr int PAIRS = 256;
 
 __global__ void __launch_bounds__(256)
 k_project_feat(gpn_project_args_t a, long long n_pairs) {
   __shared__ float sP[GPN_MAX_VIEWS * 12];
   __shared__ float sPos[GPN_MAX_VIEWS * 3];
   __shared__ __attribute__((aligned(16))) float sOut[PAIRS * 36];
+  // taps of the pairs: [0] feature map, [1] RGB image; info = valid bits (vx0 vx1 vy0 vy1) | view << 4
+  __shared__ int sX0[2][PAIRS], sY0[2][PAIRS], sInfo[2][PAIRS];
+  __shared__ float sW[2][4][PAIRS];
   const int tid = threadIdx.x;
   for (int i = tid; i < a.V * 12; i += 256) sP[i] = a.proj[(i / 12) * 16 + (i % 12)];
   for (int i = tid; i < a.V * 3; i += 256) sPos[i] = a.src_pos[i];
   __syncthreads();
-  const int slot = tid >> 3, q = tid & 7;
   // 35 channels; rows of the output are LD floats apart (36 on the fused path: 16-byte aligned rows,
   // channels OC.. are written as zeros)
   const int OC = 3 + a.feat_c, LD = a.rgb_feat_ld > 0 ? a.rgb_feat_ld : OC;
   const bool gather = a.rgb_feat != nullptr;  // false: geometry only (pix / mask / ray_diff)
+  const bool small = n_pairs < 0x7fffffffLL;  // 32-bit index arithmetic (a 64-bit division is ~100 instructions)
 
   for (long long base = (long long)blockIdx.x * PAIRS; base < n_pairs;
        base += (long long)gridDim.x * PAIRS) {
-    const long long pair = base + slot;
-    if (pair < n_pairs) {
-      const long long n = pair / a.V;
-      const int v = (int)(pair - n * a.V);
-      const float x = a.xyz[n * 3 + 0], y = a.xyz[n * 3 + 1], z = a.xyz[n * 3 + 2];
-      const GpnPix pp = gpn_project(sP + v * 12, x, y, z);
-      // 32-channel feature map, NHWC: one float4 per lane and tap
-      if (gather) {
-        const GpnTaps t = gpn_taps(pp.px, pp.py, a.img_h, a.img_w, a.feat_h, a.feat_w);
-        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* fm = a.feat + (size_t)v * a.feat_h * a.feat_w * a.feat_c + q * 4;
-        const size_t rs = (size_t)a.feat_w * a.feat_c;
-        const size_t o00 = (size_t)t.y0 * rs + (size_t)t.x0 * a.feat_c;
-        float4 vnw = zero4, vne = zero4, vsw = zero4, vse = zero4;
-        if (t.vy0 && t.vx0) vnw = *reinterpret_cast<const float4*>(fm + o00);
-        if (t.vy0 && t.vx1) vne = *reinterpret_cast<const float4*>(fm + o00 + a.feat_c);
-        if (t.vy1 && t.vx0) vsw = *reinterpret_cast<const float4*>(fm + o00 + rs);
-        if (t.vy1 && t.vx1) vse = *reinterpret_cast<const float4*>(fm + o00 + rs + a.feat_c);
-        float* o = sOut + slot * LD + 3 + q * 4;
-        o[0] = gpn_bilerp(vnw.x, vne.x, vsw.x, vse.x, t);
-        o[1] = gpn_bilerp(vnw.y, vne.y, vsw.y, vse.y, t);
-        o[2] = gpn_bilerp(vnw.z, vne.z, vsw.z, vse.z, t);
-        o[3] = gpn_bilerp(vnw.w, vne.w, vsw.w, vse.w, t);
-      }
-      if (q < 3) {  // RGB image [V,H,W,3], channel q
-        const GpnTaps t = gpn_taps(pp.px, pp.py, a.img_h, a.img_w, a.rgb_h, a.rgb_w);
-        const float* im = a.rgb + (size_t)v * a.rgb_h * a.rgb_w * 3 + q;
-        const size_t rs = (size_t)a.rgb_w * 3;
-        const size_t o00 = (size_t)t.y0 * rs + (size_t)t.x0 * 3;
-        float vnw = 0.f, vne = 0.f, vsw = 0.f, vse = 0.f;
-        if (gather && t.vy0 && t.vx0) vnw = im[o00];
-        if (gather && t.vy0 && t.vx1) vne = im[o00 + 3];
-        if (gather && t.vy1 && t.vx0) vsw = im[o00 + rs];
-        if (gather && t.vy1 && t.vx1) vse = im[o00 + rs + 3];
-        if (gather) sOut[slot * LD + q] = gpn_bilerp(vnw, vne, vsw, vse, t);
-        if (q == 0 && a.taps) {
-          a.taps[((size_t)v * a.N + n) * 2 + 0] = t.x0;
-          a.taps[((size_t)v * a.N + n) * 2 + 1] = t.y0;
+    {  // ---- phase 1: pair base + tid
+      const long long pair = base + tid;
+      if (pair < n_pairs) {
+        long long n;
+        int v;
+        if (small) {
+          const unsigned pn = (unsigned)pair / (unsigned)a.V;
+          n = pn, v = (int)((unsigned)pair - pn * (unsigned)a.V);
+        } else {
+          n = pair / a.V, v = (int)(pair - n * a.V);
         }
-      } else if (q == 3) {  // mask (projection.py:133-138)
-        if (gather)
-          for (int c = OC; c < LD; ++c) sOut[slot * LD + c] = 0.0f;
+        const float x = a.xyz[n * 3 + 0], y = a.xyz[n * 3 + 1], z = a.xyz[n * 3 + 2];
+        const GpnPix pp = gpn_project(sP + v * 12, x, y, z);
+        const GpnTaps tr = gpn_taps(pp.px, pp.py, a.img_h, a.img_w, a.rgb_h, a.rgb_w);
+        if (gather) {
+          const GpnTaps tf = gpn_taps(pp.px, pp.py, a.img_h, a.img_w, a.feat_h, a.feat_w);
+          sX0[0][tid] = tf.x0, sY0[0][tid] = tf.y0;
+          sInfo[0][tid] = (tf.vx0 ? 1 : 0) | (tf.vx1 ? 2 : 0) | (tf.vy0 ? 4 : 0) | (tf.vy1 ? 8 : 0) | (v << 4);
+          sW[0][0][tid] = tf.nw, sW[0][1][tid] = tf.ne, sW[0][2][tid] = tf.sw, sW[0][3][tid] = tf.se;
+          sX0[1][tid] = tr.x0, sY0[1][tid] = tr.y0;
+          sInfo[1][tid] = (tr.vx0 ? 1 : 0) | (tr.vx1 ? 2 : 0) | (tr.vy0 ? 4 : 0) | (tr.vy1 ? 8 : 0) | (v << 4);
+          sW[1][0][tid] = tr.nw, sW[1][1][tid] = tr.ne, sW[1][2][tid] = tr.sw, sW[1][3][tid] = tr.se;
+        }
+        if (a.taps) {
+          a.taps[((size_t)v * a.N + n) * 2 + 0] = tr.x0;
+          a.taps[((size_t)v * a.N + n) * 2 + 1] = tr.y0;
+        }
+        // mask (projection.py:133-138)
         const bool m = pp.front && gpn_inbound(pp.px, pp.py, a.img_h, a.img_w);
         if (a.mask) a.mask[pair] = m ? 1.0f : 0.0f;
         if (a.front) a.front[(size_t)v * a.N + n] = pp.front ? 1 : 0;
@@ -100,23 +97,73 @@ k_project_feat(gpn_project_args_t a, long long n_pairs) {
           a.pix[((size_t)v * a.N + n) * 2 + 0] = pp.px;
           a.pix[((size_t)v * a.N + n) * 2 + 1] = pp.py;
         }
-      } else if (q == 4 && a.ray_diff) {  // ray_diff (projection.py:65-82)
-        float ax = a.qry_pos[0] - x, ay = a.qry_pos[1] - y, az = a.qry_pos[2] - z;
-        const float na = sqrtf(ax * ax + ay * ay + az * az) + 1e-6f;
-        ax /= na, ay /= na, az /= na;
-        float bx = sPos[v * 3 + 0] - x, by = sPos[v * 3 + 1] - y, bz = sPos[v * 3 + 2] - z;
-        const float nb = sqrtf(bx * bx + by * by + bz * bz) + 1e-6f;
-        bx /= nb, by /= nb, bz /= nb;
-        const float dx = ax - bx, dy = ay - by, dz = az - bz;
-        float nd = sqrtf(dx * dx + dy * dy + dz * dz);
-        const float dot = ax * bx + ay * by + az * bz;
-        nd = nd < 1e-6f ? 1e-6f : nd;
-        *reinterpret_cast<float4*>(a.ray_diff + pair * 4) = make_float4(dx / nd, dy / nd, dz / nd, dot);
+        if (a.ray_diff) {  // ray_diff (projection.py:65-82)
+          float ax = a.qry_pos[0] - x, ay = a.qry_pos[1] - y, az = a.qry_pos[2] - z;
+          const float na = sqrtf(ax * ax + ay * ay + az * az) + 1e-6f;
+          ax /= na, ay /= na, az /= na;
+          float bx = sPos[v * 3 + 0] - x, by = sPos[v * 3 + 1] - y, bz = sPos[v * 3 + 2] - z;
+          const float nb = sqrtf(bx * bx + by * by + bz * bz) + 1e-6f;
+          bx /= nb, by /= nb, bz /= nb;
+          const float dx = ax - bx, dy = ay - by, dz = az - bz;
+          float nd = sqrtf(dx * dx + dy * dy + dz * dz);
+          const float dot = ax * bx + ay * by + az * bz;
+          nd = nd < 1e-6f ? 1e-6f : nd;
+          *reinterpret_cast<float4*>(a.ray_diff + pair * 4) = make_float4(dx / nd, dy / nd, dz / nd, dot);
+        }
       }
     }
     if (!gather) continue;  // uniform across the block
     __syncthreads();
-    // coalesced copy-out of this block's contiguous [pairs, OC] span
+    // ---- phase 2: 8 lanes per pair, 32 pairs per pass
+    const int q = tid & 7;
+    for (int sub = 0; sub < PAIRS / 32; ++sub) {
+      const int slot = sub * 32 + (tid >> 3);
+      if (base + slot < n_pairs) {
+        GpnTaps t;
+        {
+          const int info = sInfo[0][slot];
+          const int v = info >> 4;
+          t.x0 = sX0[0][slot], t.y0 = sY0[0][slot];
+          t.vx0 = info & 1, t.vx1 = info & 2, t.vy0 = info & 4, t.vy1 = info & 8;
+          t.nw = sW[0][0][slot], t.ne = sW[0][1][slot], t.sw = sW[0][2][slot], t.se = sW[0][3][slot];
+          // 32-channel feature map, NHWC: one float4 per lane and tap
+          const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          const float* fm = a.feat + (size_t)v * a.feat_h * a.feat_w * a.feat_c + q * 4;
+          const size_t rs = (size_t)a.feat_w * a.feat_c;
+          const size_t o00 = (size_t)t.y0 * rs + (size_t)t.x0 * a.feat_c;
+          float4 vnw = zero4, vne = zero4, vsw = zero4, vse = zero4;
+          if (t.vy0 && t.vx0) vnw = *reinterpret_cast<const float4*>(fm + o00);
+          if (t.vy0 && t.vx1) vne = *reinterpret_cast<const float4*>(fm + o00 + a.feat_c);
+          if (t.vy1 && t.vx0) vsw = *reinterpret_cast<const float4*>(fm + o00 + rs);
+          if (t.vy1 && t.vx1) vse = *reinterpret_cast<const float4*>(fm + o00 + rs + a.feat_c);
+          float* o = sOut + slot * LD + 3 + q * 4;
+          o[0] = gpn_bilerp(vnw.x, vne.x, vsw.x, vse.x, t);
+          o[1] = gpn_bilerp(vnw.y, vne.y, vsw.y, vse.y, t);
+          o[2] = gpn_bilerp(vnw.z, vne.z, vsw.z, vse.z, t);
+          o[3] = gpn_bilerp(vnw.w, vne.w, vsw.w, vse.w, t);
+        }
+        if (q < 3) {  // RGB image [V,H,W,3], channel q
+          const int info = sInfo[1][slot];
+          const int v = info >> 4;
+          t.x0 = sX0[1][slot], t.y0 = sY0[1][slot];
+          t.vx0 = info & 1, t.vx1 = info & 2, t.vy0 = info & 4, t.vy1 = info & 8;
+          t.nw = sW[1][0][slot], t.ne = sW[1][1][slot], t.sw = sW[1][2][slot], t.se = sW[1][3][slot];
+          const float* im = a.rgb + (size_t)v * a.rgb_h * a.rgb_w * 3 + q;
+          const size_t rs = (size_t)a.rgb_w * 3;
+          const size_t o00 = (size_t)t.y0 * rs + (size_t)t.x0 * 3;
+          float vnw = 0.f, vne = 0.f, vsw = 0.f, vse = 0.f;
+          if (t.vy0 && t.vx0) vnw = im[o00];
+          if (t.vy0 && t.vx1) vne = im[o00 + 3];
+          if (t.vy1 && t.vx0) vsw = im[o00 + rs];
+          if (t.vy1 && t.vx1) vse = im[o00 + rs + 3];
+          sOut[slot * LD + q] = gpn_bilerp(vnw, vne, vsw, vse, t);
+        } else if (q == 3) {
+          for (int c = OC; c < LD; ++c) sOut[slot * LD + c] = 0.0f;
+        }
+      }
+    }
+    __syncthreads();
+    // coalesced copy-out of this block's contiguous [pairs, LD] span
     const long long left = n_pairs - base;
     const int cnt = (int)(left < PAIRS ? left : PAIRS) * LD;
     float* dst = a.rgb_feat + base * LD;

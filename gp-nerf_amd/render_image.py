@@ -62,7 +62,9 @@ def _to_host(t, tag):
         _PINNED[tag] = buf
     view = buf[: t.numel()].view(t.shape)
     view.copy_(t, non_blocking=True)
-    return view
+    done = torch.cuda.Event()
+    done.record()
+    return view, done
 
 
 def _merge(acc, Hs, Ws):
@@ -75,10 +77,12 @@ def _merge(acc, Hs, Ws):
             if k == "random_sigma":
                 continue
             cat = torch.cat(acc[lvl][k], dim=0)
-            staged.append((lvl, k, _to_host(cat, (lvl, k)) if cat.is_cuda else cat))
-    if staged:
-        torch.cuda.synchronize()
-    for lvl, k, host in staged:
+            staged.append((lvl, k) + (_to_host(cat, (lvl, k)) if cat.is_cuda else (cat, None)))
+    # every copy has been queued; each output is cloned out of its page-locked buffer as soon as ITS
+    # copy has landed, while the later ones are still in flight (the clones cost more than the copies)
+    for lvl, k, host, done in staged:
+        if done is not None:
+            done.synchronize()
         cat = host.clone()
         if k == "feats_out":
             acc[lvl][k] = cat.reshape((Hs, Ws, 512, -1)).squeeze()

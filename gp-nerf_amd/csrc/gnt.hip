@@ -100,10 +100,15 @@ static int set_lds_limit(const void* fn, size_t bytes) {
   return GPN_OK;
 }
 
-static int persistent_grid(long long work_items) {
-  const long long cus = gpn_num_cus();
+static int persistent_grid(long long work_items, int blocks_per_cu = 1) {
+  const long long cus = (long long)gpn_num_cus() * blocks_per_cu;
   return (int)(work_items < cus ? (work_items < 1 ? 1 : work_items) : cus);
 }
+// workgroups per CU of k_rgbfeat (124 VGPRs, 28 KB of LDS: two fit): four waves per SIMD in flight
+// take 9 % off that memory-bound kernel; the same setting made k_qpos 5 % slower (measured, A/B)
+#ifndef GPN_MEM_BPC
+#define GPN_MEM_BPC 2
+#endif
 
 // sin and cos of one fp32 argument.  |x| <= 1e5 (the encodings reach 2^9 |coordinate|: ~5e3 in a room):
 // four-term Cody-Waite reduction by pi/2 on fused multiply-adds (the terms sum to pi/2 to 2^-70; the
@@ -2022,7 +2027,7 @@ extern "C" int gpn_rgbfeat(const gpn_linear_t* fc0, const gpn_linear_t* fc2, con
               "gpn_rgbfeat: rgb_feat with rows of a multiple of 4 floats must be 16-byte aligned");
   const bool spl = gpn_precision() == GPN_PREC_BF16X3;
   const size_t lds = sizeof(float) * (wimg_floats(spl, 64, 3, RF_LD0) + wimg_floats(spl, 64, 4, LDW) + 128);
-  const int grid = persistent_grid(((long long)N + (RF_TPB / 4) - 1) / (RF_TPB / 4));
+  const int grid = persistent_grid(((long long)N + (RF_TPB / 4) - 1) / (RF_TPB / 4), GPN_MEM_BPC);
   GpnStageTimer timer_k_rgbfeat_(GPN_ST_RGBFEAT, (hipStream_t)stream);
   if (spl)
     hipLaunchKernelGGL(k_rgbfeat<true>, dim3(grid), dim3(RF_TPB), lds, (hipStream_t)stream, *fc0, *fc2,

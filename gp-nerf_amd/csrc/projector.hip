@@ -31,7 +31,7 @@ __global__ void k_repack_nhwc(const float* __restrict__ src, float* __restrict__
 }
 
 // ---------------------------------------------------------------- RGB + feature gather, mask, ray_diff
-// 256 threads work on 256 (point, view) pairs at a time, in two phases:
+// A workgroup of PAIRS threads works on PAIRS (point, view) pairs at a time, in two phases:
 //   1. one LANE per pair does the per-pair arithmetic once -- projection, in-front / in-bounds mask,
 //      the tap positions and bilinear weights on both maps (8 correctly rounded divisions), ray_diff
 //      (9 divisions, 3 square roots) -- writes mask / ray_diff / the optional geometry outputs
@@ -40,9 +40,12 @@ __global__ void k_repack_nhwc(const float* __restrict__ src, float* __restrict__
 //      one RGB channel each; rows go through LDS and leave as one contiguous, coalesced span.
 // (With 8 lanes per pair doing phase 1 as well -- the first form of this kernel -- every wave ran the
 // whole per-pair arithmetic for 8 pairs only: it was instruction-bound at 2.7 TB/s.)
-constexpr int PAIRS = 256;
+#ifndef GPN_PROJ_PAIRS
+#define GPN_PROJ_PAIRS 256  // measured per step: 256 -> 0.36 ms, 128 -> 0.42 ms, 64 -> 0.43 ms
+#endif
+constexpr int PAIRS = GPN_PROJ_PAIRS;  // pairs per pass = threads per workgroup
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(PAIRS)
 k_project_feat(gpn_project_args_t a, long long n_pairs) {
   __shared__ float sP[GPN_MAX_VIEWS * 12];
   __shared__ float sPos[GPN_MAX_VIEWS * 3];
@@ -51,8 +54,8 @@ k_project_feat(gpn_project_args_t a, long long n_pairs) {
   __shared__ int sX0[2][PAIRS], sY0[2][PAIRS], sInfo[2][PAIRS];
   __shared__ float sW[2][4][PAIRS];
   const int tid = threadIdx.x;
-  for (int i = tid; i < a.V * 12; i += 256) sP[i] = a.proj[(i / 12) * 16 + (i % 12)];
-  for (int i = tid; i < a.V * 3; i += 256) sPos[i] = a.src_pos[i];
+  for (int i = tid; i < a.V * 12; i += PAIRS) sP[i] = a.proj[(i / 12) * 16 + (i % 12)];
+  for (int i = tid; i < a.V * 3; i += PAIRS) sPos[i] = a.src_pos[i];
   __syncthreads();
   // 35 channels; rows of the output are LD floats apart (36 on the fused path: 16-byte aligned rows,
   // channels OC.. are written as zeros)
@@ -114,10 +117,10 @@ k_project_feat(gpn_project_args_t a, long long n_pairs) {
     }
     if (!gather) continue;  // uniform across the block
     __syncthreads();
-    // ---- phase 2: 8 lanes per pair, 32 pairs per pass
+    // ---- phase 2: 8 lanes per pair
     const int q = tid & 7;
-    for (int sub = 0; sub < PAIRS / 32; ++sub) {
-      const int slot = sub * 32 + (tid >> 3);
+    for (int sub = 0; sub < 8; ++sub) {  // PAIRS / 8 pairs per pass
+      const int slot = sub * (PAIRS / 8) + (tid >> 3);
       if (base + slot < n_pairs) {
         GpnTaps t;
         {
@@ -168,11 +171,11 @@ k_project_feat(gpn_project_args_t a, long long n_pairs) {
     const int cnt = (int)(left < PAIRS ? left : PAIRS) * LD;
     float* dst = a.rgb_feat + base * LD;
     if (((base * LD) & 3) == 0) {
-      for (int i = tid * 4; i + 3 < cnt; i += 256 * 4)
+      for (int i = tid * 4; i + 3 < cnt; i += PAIRS * 4)
         *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(sOut + i);
-      for (int i = (cnt & ~3) + tid; i < cnt; i += 256) dst[i] = sOut[i];
+      for (int i = (cnt & ~3) + tid; i < cnt; i += PAIRS) dst[i] = sOut[i];
     } else {
-      for (int i = tid; i < cnt; i += 256) dst[i] = sOut[i];
+      for (int i = tid; i < cnt; i += PAIRS) dst[i] = sOut[i];
     }
     __syncthreads();
   }
@@ -261,7 +264,7 @@ extern "C" int gpn_project_gather(const gpn_project_args_t* a, gpn_stream_t stre
     const long long blocks = (n_pairs + PAIRS - 1) / PAIRS;
     const int grid = (int)(blocks < (long long)cus * 16 ? blocks : (long long)cus * 16);
     GpnStageTimer timer_k_project_feat_(GPN_ST_PROJECT, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_project_feat, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, n_pairs);
+    hipLaunchKernelGGL(k_project_feat, dim3(grid), dim3(PAIRS), 0, (hipStream_t)stream, *a, n_pairs);
     GPN_LAUNCH_CHECK("k_project_feat");
   }
   if (want_deep) {

@@ -7,7 +7,7 @@ for rep in 1 2; do
     python - $lib <<'PY'
 import json,sys
 l=[x for x in open("/tmp/ab.log") if x.startswith("{")][-1]; d=json.loads(l)
-print("%-32s rays/s %.0f  ms/step %.3f  %s" % (sys.argv[1], d["value"], d["ms_per_step"], {k: d["stage_ms_one_step"][k] for k in ("rgbfeat","qpos","view_attn","ff","ray_attn","sem")}), flush=True)
+print("%-32s rays/s %.0f  ms/step %.3f  %s" % (sys.argv[1], d["value"], d["ms_per_step"], {k: d["stage_ms_one_step"][k] for k in ("project","rgbfeat","view_attn","ff","ray_attn","sem")}), flush=True)
 PY
   done
 done

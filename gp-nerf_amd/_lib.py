@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GPN_LIB: developer override used to A/B kernel build variants; the default is the in-tree library
 LIB_PATH = os.environ.get("GPN_LIB") or os.path.join(_HERE, "csrc", "libgpnerf_hip.so")
 
+ABI_VERSION = 2
 MAX_DEPTH = 8
 MAX_VIEWS = 32
 MAX_SAMPLES = 128
@@ -47,6 +48,7 @@ class RayLayer(C.Structure):
 
 class GntWeights(C.Structure):
     _fields_ = [("trans_depth", C.c_int), ("in_feat_ch", C.c_int),
+                ("precision", C.c_int), ("reserved_", C.c_int),
                 ("rgbfeat0", Linear), ("rgbfeat2", Linear),
                 ("view", ViewLayer * MAX_DEPTH), ("ray", RayLayer * MAX_DEPTH),
                 ("qfc0", Linear * MAX_DEPTH), ("qfc2", Linear * MAX_DEPTH),
@@ -94,23 +96,23 @@ _SIGS = {
     "gpn_project_gather": (C.c_int, [C.POINTER(ProjectArgs), _P]),
     "gpn_posenc": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "gpn_rgbfeat": (C.c_int, [C.POINTER(Linear), C.POINTER(Linear), _P, C.c_int, C.c_int, C.c_int,
-                              C.c_int, _P, _P, _P, _P]),
+                              C.c_int, _P, _P, _P, C.c_int, _P]),
     "gpn_view_attn": (C.c_int, [C.POINTER(ViewLayer), _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P,
-                                C.c_int, _P, C.c_int, _P]),
+                                C.c_int, _P, C.c_int, C.c_int, _P]),
     "gpn_view_fold": (C.c_int, [C.POINTER(ViewLayer), _P, _P]),
     "gpn_vis_order_scratch_bytes": (C.c_size_t, []),
     "gpn_vis_order": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P]),
-    "gpn_ff": (C.c_int, [_P, _P, C.POINTER(Linear), C.POINTER(Linear), _P, C.c_int, _P, _P]),
-    "gpn_qpos": (C.c_int, [C.POINTER(Linear), C.POINTER(Linear), _P, _P, _P, C.c_int, C.c_int, _P, _P]),
-    "gpn_ray_attn": (C.c_int, [C.POINTER(RayLayer), _P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P]),
+    "gpn_ff": (C.c_int, [_P, _P, C.POINTER(Linear), C.POINTER(Linear), _P, C.c_int, _P, C.c_int, _P]),
+    "gpn_qpos": (C.c_int, [C.POINTER(Linear), C.POINTER(Linear), _P, _P, _P, C.c_int, C.c_int, _P,
+                           C.c_int, _P]),
+    "gpn_ray_attn": (C.c_int, [C.POINTER(RayLayer), _P, C.c_int, C.c_int, _P, _P, C.c_int, _P,
+                               C.c_int, _P]),
     "gpn_sem_aggregate": (C.c_int, [C.POINTER(SemArgs), _P]),
     "gpn_heads": (C.c_int, [C.POINTER(GntWeights), _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P,
                             _P]),
     "gpn_gnt_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "gpn_gnt_forward": (C.c_int, [C.POINTER(GntWeights), _P, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int,
                                   C.c_int, C.POINTER(SemArgs), _P, _P, _P, _P, C.c_size_t, _P]),
-    "gpn_set_precision": (C.c_int, [C.c_int]),
-    "gpn_get_precision": (C.c_int, []),
     "gpn_timing_begin": (C.c_int, [C.c_uint, C.c_int]),
     "gpn_timing_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
 }
@@ -135,7 +137,7 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.gpn_abi_version() != 1:
+        if h.gpn_abi_version() != ABI_VERSION:
             raise RuntimeError("gp-nerf_amd: ABI version mismatch in " + LIB_PATH)
         _lib = h
     return _lib
@@ -199,14 +201,13 @@ class stage_timing:
         return False
 
 
-PRECISIONS = {"fp32": 0, "bf16x3": 1}
+PRECISIONS = {"fp32": 0, "bf16x3": 1}  # GPN_PREC_* of include/gpnerf_hip.h
 
 
-def set_precision(mode):
-    """'fp32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 MFMA, fp32 accumulate; see the header)."""
-    check(lib().gpn_set_precision(PRECISIONS[mode]), "gpn_set_precision")
-
-
-def get_precision():
-    code = lib().gpn_get_precision()
-    return [k for k, v in PRECISIONS.items() if v == code][0]
+def precision_code(mode):
+    """'fp32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 MFMA, fp32 accumulate) -> GPN_PREC_*.  The mode
+    is an argument of every call (ABI 2): there is no process-wide switch."""
+    try:
+        return PRECISIONS[mode]
+    except KeyError:
+        raise ValueError("precision must be one of %s (got %r)" % (sorted(PRECISIONS), mode)) from None

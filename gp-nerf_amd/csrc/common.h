@@ -34,8 +34,14 @@ class GpnStageTimer {
 
  private:
   int slot_;
+  unsigned session_;
   hipStream_t stream_;
 };
 
-// Arithmetic mode of the GNT linear layers (gpn_set_precision in the header).
-int gpn_precision();
+// N = R*S points and N*V pairs are indexed with 32-bit ints in the kernels and the C-ABI.
+#define GPN_REQUIRE_INT_RANGE(R, S, V, name)                                                     \
+  GPN_REQUIRE((long long)(R) * (S) * ((V) > 0 ? (V) : 1) <= 2147483647LL,                        \
+              "%s: R*S*V = %lld does not fit a 32-bit int (render in smaller chunks)", (name),   \
+              (long long)(R) * (S) * ((V) > 0 ? (V) : 1))
+#define GPN_REQUIRE_PREC(p, name)                                                                \
+  GPN_REQUIRE((p) == GPN_PREC_FP32 || (p) == GPN_PREC_BF16X3, "%s: unknown precision %d", (name), (int)(p))

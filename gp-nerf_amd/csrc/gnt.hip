@@ -2013,7 +2013,8 @@ extern "C" int gpn_posenc(const float* pts, const float* ray_d, int R, int S, fl
 
 extern "C" int gpn_rgbfeat(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* rgb_feat,
                            int N, int V, int in_ch, int in_ld, const float* mask, float* feat,
-                           float* q0, gpn_stream_t stream) {
+                           float* q0, int precision, gpn_stream_t stream) {
+  GPN_REQUIRE_PREC(precision, "gpn_rgbfeat");
   if (N == 0) return GPN_OK;  // empty batch (pointers may be null)
   GPN_REQUIRE(fc0 && fc2 && rgb_feat && feat && q0, "gpn_rgbfeat: null pointer");
   REQ_LIN(*fc2, "gpn_rgbfeat.fc2");
@@ -2025,7 +2026,8 @@ extern "C" int gpn_rgbfeat(const gpn_linear_t* fc0, const gpn_linear_t* fc2, con
   GPN_REQUIRE(in_ld >= in_ch && in_ld <= 48, "gpn_rgbfeat: in_ld must be 0 or in [in_ch,48] (got %d)", in_ld);
   GPN_REQUIRE((in_ld & 3) != 0 || aligned16(rgb_feat),
               "gpn_rgbfeat: rgb_feat with rows of a multiple of 4 floats must be 16-byte aligned");
-  const bool spl = gpn_precision() == GPN_PREC_BF16X3;
+  GPN_REQUIRE_INT_RANGE(N, 1, V, "gpn_rgbfeat");
+  const bool spl = precision == GPN_PREC_BF16X3;
   const size_t lds = sizeof(float) * (wimg_floats(spl, 64, 3, RF_LD0) + wimg_floats(spl, 64, 4, LDW) + 128);
   const int grid = persistent_grid(((long long)N + (RF_TPB / 4) - 1) / (RF_TPB / 4), GPN_MEM_BPC);
   GpnStageTimer timer_k_rgbfeat_(GPN_ST_RGBFEAT, (hipStream_t)stream);
@@ -2046,6 +2048,7 @@ extern "C" int gpn_vis_order(const float* mask, int N, int V, int32_t* perm, voi
   if (N == 0) return GPN_OK;
   GPN_REQUIRE(mask && perm && scratch, "gpn_vis_order: null pointer");
   GPN_REQUIRE(N > 0 && V >= 1 && V <= GPN_MAX_VIEWS, "gpn_vis_order: bad shape");
+  GPN_REQUIRE_INT_RANGE(N, 1, V, "gpn_vis_order");
   int* hist = static_cast<int*>(scratch);
   int* cursor = hist + VIS_BINS;
   hipStream_t st = (hipStream_t)stream;
@@ -2072,7 +2075,8 @@ extern "C" int gpn_view_fold(const gpn_view_layer_t* L, float* out, gpn_stream_t
 extern "C" int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const float* feat,
                              const float* ray_diff, const float* mask, const int32_t* perm, int N,
                              int V, float* q_out, float* hidden, int hidden_ld, float* stats,
-                             int stats_ld, gpn_stream_t stream) {
+                             int stats_ld, int precision, gpn_stream_t stream) {
+  GPN_REQUIRE_PREC(precision, "gpn_view_attn");
   if (N == 0) return GPN_OK;  // empty batch (pointers may be null)
   GPN_REQUIRE(L && q_in && feat && ray_diff && mask && q_out, "gpn_view_attn: null pointer");
   REQ_LIN(L->q, "gpn_view_attn.q");
@@ -2089,7 +2093,8 @@ extern "C" int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const
               "gpn_view_attn: hidden_ld must be a multiple of 4 and >= 8 (got %d)", hidden_ld);
   GPN_REQUIRE(!stats || (stats_ld >= C64 && stats_ld % 4 == 0),
               "gpn_view_attn: stats_ld must be a multiple of 4 and >= %d (got %d)", C64, stats_ld);
-  const bool spl = gpn_precision() == GPN_PREC_BF16X3;
+  GPN_REQUIRE_INT_RANGE(N, 1, V, "gpn_view_attn");
+  const bool spl = precision == GPN_PREC_BF16X3;
   const bool fold = spl && L->folded != nullptr;
   const size_t lds = sizeof(float) * view_lds_floats(spl) + (VA_TPB / 64) * 2 * VA_SLOT_BYTES;
   const void* fn = fold ? reinterpret_cast<const void*>(k_view_attn<true, true>)
@@ -2116,15 +2121,15 @@ extern "C" int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const
 
 extern "C" int gpn_ff(const float* norm_w, const float* norm_b, const gpn_linear_t* fc1,
                       const gpn_linear_t* fc2, const float* x_in, int N, float* x_out,
-                      gpn_stream_t stream) {
+                      int precision, gpn_stream_t stream) {
+  GPN_REQUIRE_PREC(precision, "gpn_ff");
   if (N == 0) return GPN_OK;  // empty batch (pointers may be null)
   GPN_REQUIRE(norm_w && norm_b && fc1 && fc2 && x_in && x_out, "gpn_ff: null pointer");
   REQ_LIN(*fc1, "gpn_ff.fc1");
   REQ_LIN(*fc2, "gpn_ff.fc2");
   GPN_REQUIRE(aligned16(x_in) && aligned16(x_out), "gpn_ff: tensors must be 16-byte aligned");
   GPN_REQUIRE(N >= 0, "gpn_ff: bad N");
-  if (N == 0) return GPN_OK;
-  const bool spl = gpn_precision() == GPN_PREC_BF16X3;
+  const bool spl = precision == GPN_PREC_BF16X3;
   const size_t lds = sizeof(float) * ff_lds_floats(spl);
   int rc = set_lds_limit(spl ? reinterpret_cast<const void*>(k_ff<true>)
                              : reinterpret_cast<const void*>(k_ff<false>), lds);
@@ -2149,7 +2154,8 @@ extern "C" int gpn_ff(const float* norm_w, const float* norm_b, const gpn_linear
 
 extern "C" int gpn_qpos(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* q_in,
                         const float* emb_pt, const float* emb_ray, int N, int S, float* q_out,
-                        gpn_stream_t stream) {
+                        int precision, gpn_stream_t stream) {
+  GPN_REQUIRE_PREC(precision, "gpn_qpos");
   if (N == 0) return GPN_OK;  // empty batch (pointers may be null)
   GPN_REQUIRE(fc0 && fc2 && q_in && emb_pt && emb_ray && q_out, "gpn_qpos: null pointer");
   GPN_REQUIRE(fc0->w, "gpn_qpos: null weight");
@@ -2157,8 +2163,7 @@ extern "C" int gpn_qpos(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const 
   GPN_REQUIRE(aligned16(q_in) && aligned16(emb_pt) && aligned16(emb_ray) && aligned16(q_out),
               "gpn_qpos: tensors must be 16-byte aligned");
   GPN_REQUIRE(N >= 0 && S >= 1 && N % S == 0, "gpn_qpos: N must be a multiple of S >= 1 (got N=%d S=%d)", N, S);
-  if (N == 0) return GPN_OK;
-  const bool spl = gpn_precision() == GPN_PREC_BF16X3;
+  const bool spl = precision == GPN_PREC_BF16X3;
   const size_t lds = sizeof(float) * qp_lds_floats(spl);
   int rc = set_lds_limit(spl ? reinterpret_cast<const void*>(k_qpos<true>)
                              : reinterpret_cast<const void*>(k_qpos<false>), lds);
@@ -2192,14 +2197,16 @@ static int launch_ray_attn_p(const gpn_ray_layer_t* L, const float* x_in, int R,
 
 template <int NT>
 static int launch_ray_attn(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,
-                           float* abar, int abar_ld, float* weights, hipStream_t stream) {
-  if (gpn_precision() == GPN_PREC_BF16X3)
+                           float* abar, int abar_ld, float* weights, int precision, hipStream_t stream) {
+  if (precision == GPN_PREC_BF16X3)
     return launch_ray_attn_p<NT, true>(L, x_in, R, S, x_out, abar, abar_ld, weights, stream);
   return launch_ray_attn_p<NT, false>(L, x_in, R, S, x_out, abar, abar_ld, weights, stream);
 }
 
 extern "C" int gpn_ray_attn(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,
-                            float* abar, int abar_ld, float* weights, gpn_stream_t stream) {
+                            float* abar, int abar_ld, float* weights, int precision,
+                            gpn_stream_t stream) {
+  GPN_REQUIRE_PREC(precision, "gpn_ray_attn");
   if (R == 0) return GPN_OK;  // empty batch (pointers may be null)
   GPN_REQUIRE(L && x_in && x_out, "gpn_ray_attn: null pointer");
   REQ_LIN(L->q, "gpn_ray_attn.q");
@@ -2211,17 +2218,17 @@ extern "C" int gpn_ray_attn(const gpn_ray_layer_t* L, const float* x_in, int R, 
               "gpn_ray_attn: samples per ray must be in [1,%d] (got %d)", GPN_MAX_SAMPLES, S);
   GPN_REQUIRE(aligned16(x_in) && aligned16(x_out), "gpn_ray_attn: tensors must be 16-byte aligned");
   GPN_REQUIRE(!abar || abar_ld >= 4, "gpn_ray_attn: abar_ld must be >= 4 (got %d)", abar_ld);
-  if (R == 0) return GPN_OK;
+  GPN_REQUIRE_INT_RANGE(R, S, 1, "gpn_ray_attn");
   hipStream_t st = (hipStream_t)stream;
   switch ((S + 15) / 16) {
-    case 1: return launch_ray_attn<1>(L, x_in, R, S, x_out, abar, abar_ld, weights, st);
-    case 2: return launch_ray_attn<2>(L, x_in, R, S, x_out, abar, abar_ld, weights, st);
-    case 3: return launch_ray_attn<3>(L, x_in, R, S, x_out, abar, abar_ld, weights, st);
-    case 4: return launch_ray_attn<4>(L, x_in, R, S, x_out, abar, abar_ld, weights, st);
-    case 5: return launch_ray_attn<5>(L, x_in, R, S, x_out, abar, abar_ld, weights, st);
-    case 6: return launch_ray_attn<6>(L, x_in, R, S, x_out, abar, abar_ld, weights, st);
-    case 7: return launch_ray_attn<7>(L, x_in, R, S, x_out, abar, abar_ld, weights, st);
-    default: return launch_ray_attn<8>(L, x_in, R, S, x_out, abar, abar_ld, weights, st);
+    case 1: return launch_ray_attn<1>(L, x_in, R, S, x_out, abar, abar_ld, weights, precision, st);
+    case 2: return launch_ray_attn<2>(L, x_in, R, S, x_out, abar, abar_ld, weights, precision, st);
+    case 3: return launch_ray_attn<3>(L, x_in, R, S, x_out, abar, abar_ld, weights, precision, st);
+    case 4: return launch_ray_attn<4>(L, x_in, R, S, x_out, abar, abar_ld, weights, precision, st);
+    case 5: return launch_ray_attn<5>(L, x_in, R, S, x_out, abar, abar_ld, weights, precision, st);
+    case 6: return launch_ray_attn<6>(L, x_in, R, S, x_out, abar, abar_ld, weights, precision, st);
+    case 7: return launch_ray_attn<7>(L, x_in, R, S, x_out, abar, abar_ld, weights, precision, st);
+    default: return launch_ray_attn<8>(L, x_in, R, S, x_out, abar, abar_ld, weights, precision, st);
   }
 }
 
@@ -2230,6 +2237,7 @@ extern "C" int gpn_sem_aggregate(const gpn_sem_args_t* a, gpn_stream_t stream) {
   if (a->R == 0) return GPN_OK;  // empty batch
   GPN_REQUIRE(a->R >= 0 && a->S >= 1 && a->V >= 1 && a->V <= GPN_MAX_VIEWS && a->depth >= 1 &&
                   a->depth <= GPN_MAX_DEPTH, "gpn_sem_aggregate: bad shape");
+  GPN_REQUIRE_INT_RANGE(a->R, a->S, a->V, "gpn_sem_aggregate");
   GPN_REQUIRE(a->mask && a->pre, "gpn_sem_aggregate: null pointer");
   GPN_REQUIRE(a->hidden && a->stats && a->abar, "gpn_sem_aggregate: null hidden / stats / abar");
   for (int l = 0; l < a->depth; ++l)
@@ -2334,6 +2342,9 @@ extern "C" int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat
               GPN_MAX_DEPTH);
   GPN_REQUIRE(R >= 0 && S >= 1 && S <= GPN_MAX_SAMPLES && V >= 1 && V <= GPN_MAX_VIEWS,
               "gpn_gnt_forward: unsupported shape R=%d S=%d V=%d", R, S, V);
+  GPN_REQUIRE_INT_RANGE(R, S, V, "gpn_gnt_forward");
+  const int prec = W->precision;
+  GPN_REQUIRE_PREC(prec, "gpn_gnt_forward (gpn_gnt_weights_t.precision)");
   const GntWs L = gnt_ws_layout(R, S, V, D);
   GPN_REQUIRE(workspace_bytes >= L.total, "gpn_gnt_forward: workspace too small (%zu < %zu)",
               workspace_bytes, L.total);
@@ -2354,7 +2365,7 @@ extern "C" int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat
   if ((rc = gpn_posenc(pts, ray_d, R, S, emb, emb_ray, stream))) return rc;
   // (mask given: the feature rows of masked pairs, which gpn_view_attn never uses, are not stored)
   if ((rc = gpn_rgbfeat(&W->rgbfeat0, &W->rgbfeat2, rgb_feat, (int)N, V, 3 + W->in_feat_ch, rgb_feat_ld,
-                        mask, feat, q, stream)))
+                        mask, feat, q, prec, stream)))
     return rc;
   for (int l = 0; l < D; ++l) {
     // side outputs for the semantic aggregation, interleaved over the layers
@@ -2364,13 +2375,13 @@ extern "C" int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat
     const gpn_view_layer_t* vl = &W->view[l];
     const gpn_ray_layer_t* rl = &W->ray[l];
     if ((rc = gpn_view_attn(vl, q, feat, ray_diff, mask, perm, (int)N, V, q, hd, D * 8, st, D * C64,
-                            stream)))
+                            prec, stream)))
       return rc;
-    if ((rc = gpn_ff(vl->ff_norm_w, vl->ff_norm_b, &vl->ff1, &vl->ff2, q, (int)N, q, stream))) return rc;
+    if ((rc = gpn_ff(vl->ff_norm_w, vl->ff_norm_b, &vl->ff1, &vl->ff2, q, (int)N, q, prec, stream))) return rc;
     if (l % 2 == 0)
-      if ((rc = gpn_qpos(&W->qfc0[l], &W->qfc2[l], q, emb, emb_ray, (int)N, S, q, stream))) return rc;
-    if ((rc = gpn_ray_attn(rl, q, R, S, q, ab, D * 4, l == D - 1 ? wts : nullptr, stream))) return rc;
-    if ((rc = gpn_ff(rl->ff_norm_w, rl->ff_norm_b, &rl->ff1, &rl->ff2, q, (int)N, q, stream))) return rc;
+      if ((rc = gpn_qpos(&W->qfc0[l], &W->qfc2[l], q, emb, emb_ray, (int)N, S, q, prec, stream))) return rc;
+    if ((rc = gpn_ray_attn(rl, q, R, S, q, ab, D * 4, l == D - 1 ? wts : nullptr, prec, stream))) return rc;
+    if ((rc = gpn_ff(rl->ff_norm_w, rl->ff_norm_b, &rl->ff1, &rl->ff2, q, (int)N, q, prec, stream))) return rc;
   }
   if (sem) {
     sem->R = R, sem->S = S, sem->V = V, sem->depth = D;

@@ -14,6 +14,10 @@ from . import _lib
 
 
 def _key(t):
+    """Identity of a device tensor's current contents.  Only valid while the tensor is alive: every
+    cache below stores the keyed tensor next to its entry, so that the caching allocator cannot hand
+    the same address to a later tensor (another image's cameras have the same shape and _version 0)
+    while the entry exists."""
     return (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
 
 
@@ -34,8 +38,8 @@ class SourceViews:
 class Projector:
     def __init__(self, device):
         self.device = device
-        self._cam_cache = {}
-        self._map_cache = {}
+        self._cam_cache = {}  # key -> (..., keyed tensor)
+        self._map_cache = {}  # role ('feat' / 'deep') -> (key, NHWC tensor, keyed tensor): one image's worth
 
     # ------------------------------------------------------------------ small helpers (API parity)
     def inbound(self, pixel_locations, h, w):
@@ -60,34 +64,44 @@ class Projector:
             P = K.bmm(torch.inverse(c2w)).contiguous()  # same CPU ops as the reference
             pos = c2w[:, :3, 3].contiguous()
             dev = train_cameras.device
-            hit = (P.to(dev), pos.to(dev), float(cams[0, 0]), float(cams[0, 1]), P)
+            # (train_cameras rides along: it keeps the keyed address from being recycled)
+            hit = (P.to(dev), pos.to(dev), float(cams[0, 0]), float(cams[0, 1]), P, train_cameras)
             if len(self._cam_cache) > 64:
                 self._cam_cache.clear()
             self._cam_cache[k] = hit
-        return hit
+        return hit[:5]
 
-    def _nhwc(self, maps):
-        """[V,C,H,W] device tensor -> cached NHWC copy."""
+    def _query_pos(self, query_camera):
+        """Camera centre of the query view as host floats; cached like _cameras."""
+        k = ("q",) + _key(query_camera)
+        hit = self._cam_cache.get(k)
+        if hit is None:
+            qc = query_camera.detach().float().cpu().reshape(-1)[-16:].reshape(4, 4)
+            hit = ((float(qc[0, 3]), float(qc[1, 3]), float(qc[2, 3])), query_camera)
+            if len(self._cam_cache) > 64:
+                self._cam_cache.clear()
+            self._cam_cache[k] = hit
+        return hit[0]
+
+    def _nhwc(self, maps, role="feat"):
+        """[V,C,H,W] device tensor -> cached NHWC copy.  One entry per role: when the next image's
+        maps arrive the previous image's copy (1.6 GB for a 640x480 deep-semantic stack) is dropped."""
         k = _key(maps)
-        hit = self._map_cache.get(k)
-        if hit is None and maps.dtype == torch.float32 and maps.is_cuda and maps.dim() == 4 and \
+        hit = self._map_cache.get(role)
+        if hit is not None and hit[0] == k:
+            return hit[1]
+        if maps.dtype == torch.float32 and maps.is_cuda and maps.dim() == 4 and \
                 maps.permute(0, 2, 3, 1).is_contiguous():
             # channels_last map (the encoders of feature_network.py emit this): already NHWC in memory
-            hit = (maps.permute(0, 2, 3, 1), maps)
-            if len(self._map_cache) > 8:
-                self._map_cache.clear()
-            self._map_cache[k] = hit
-        if hit is None:
+            nhwc = maps.permute(0, 2, 3, 1)
+        else:
             src = _lib.dev_f32(_lib.as_f32c(maps), "feature maps")
             V, Cc, H, W = src.shape
-            dst = torch.empty((V, H, W, Cc), dtype=torch.float32, device=src.device)
-            _lib.check(_lib.lib().gpn_repack_nhwc(_lib.ptr(src), _lib.ptr(dst), V, Cc, H, W,
+            nhwc = torch.empty((V, H, W, Cc), dtype=torch.float32, device=src.device)
+            _lib.check(_lib.lib().gpn_repack_nhwc(_lib.ptr(src), _lib.ptr(nhwc), V, Cc, H, W,
                                                   _lib.stream()), "gpn_repack_nhwc")
-            if len(self._map_cache) > 8:
-                self._map_cache.clear()
-            hit = (dst, maps)  # keep `maps` alive so that its data_ptr cannot be recycled
-            self._map_cache[k] = hit
-        return hit[0]
+        self._map_cache[role] = (k, nhwc, maps)  # `maps` rides along: its address cannot be recycled
+        return nhwc
 
     def prepare(self, query_camera, train_imgs, train_cameras, featmaps, deep_semantics):
         """Validate the reference-shaped inputs once and return a SourceViews for the kernels."""
@@ -97,21 +111,16 @@ class Projector:
         cams = train_cameras.squeeze(0)
         sv.proj, sv.src_pos, sv.img_h, sv.img_w, sv.proj_cpu = self._cameras(cams)
         sv.V = cams.shape[0]
-        q = self._cam_cache.get(("q",) + _key(query_camera))
-        if q is None:
-            qc = query_camera.detach().float().cpu().reshape(-1)[-16:].reshape(4, 4)
-            q = (float(qc[0, 3]), float(qc[1, 3]), float(qc[2, 3]))
-            self._cam_cache[("q",) + _key(query_camera)] = q
-        sv.qry_pos = q
+        sv.qry_pos = self._query_pos(query_camera)
         sv.rgb = _lib.dev_f32(_lib.as_f32c(train_imgs.squeeze(0)), "train_imgs")
         if sv.rgb.shape[0] != sv.V or sv.rgb.shape[-1] != 3:
             raise ValueError("train_imgs must be [1,V,H,W,3]")
         if featmaps is not None:
-            sv.feat = self._nhwc(featmaps)
+            sv.feat = self._nhwc(featmaps, "feat")
             if sv.feat.shape[0] != sv.V:
                 raise ValueError("featmaps must have one map per source view")
         if deep_semantics is not None:
-            sv.deep = self._nhwc(deep_semantics)
+            sv.deep = self._nhwc(deep_semantics, "deep")
             if sv.deep.shape[0] != sv.V:
                 raise ValueError("deep_semantics must have one map per source view")
         return sv
@@ -163,8 +172,7 @@ class Projector:
         sv = SourceViews()
         sv.proj, sv.src_pos, sv.img_h, sv.img_w, sv.proj_cpu = self._cameras(train_cameras)
         sv.V = train_cameras.shape[0]
-        qc = query_camera.detach().float().cpu().reshape(-1)[-16:].reshape(4, 4)
-        sv.qry_pos = (float(qc[0, 3]), float(qc[1, 3]), float(qc[2, 3]))
+        sv.qry_pos = self._query_pos(query_camera)
         sv.rgb = torch.empty((sv.V, 2, 2, 3), device=xyz.device)
         out = self._launch(xyz, sv, False, False, want_geom=True)
         nd = out["ray_diff"].dim()

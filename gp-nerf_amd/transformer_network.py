@@ -134,6 +134,7 @@ class GNT(nn.Module):
     def _weights(self):
         key = tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._wcache is not None and self._wcache[0] == key:
+            self._wcache[1].precision = _lib.precision_code(self.precision)
             return self._wcache[1]
         for n, p in self.named_parameters():
             if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
@@ -144,6 +145,7 @@ class GNT(nn.Module):
         W = _lib.GntWeights()
         folded = []
         W.trans_depth, W.in_feat_ch = self.trans_depth, self.in_feat_ch
+        W.precision = _lib.precision_code(self.precision)
         W.rgbfeat0, W.rgbfeat2 = _lin(self.rgbfeat_fc[0]), _lin(self.rgbfeat_fc[2])
         for i in range(self.trans_depth):
             b, L = self.view_crosstrans[i], W.view[i]
@@ -201,8 +203,7 @@ class GNT(nn.Module):
         ray_d = _lib.dev_f32(_lib.as_f32c(ray_d), "ray_d", (R, 3))
         if S < 1 or S > _lib.MAX_SAMPLES:
             raise ValueError("samples per ray must be in [1,%d] (got %d)" % (_lib.MAX_SAMPLES, S))
-        W = self._weights()
-        _lib.set_precision(self.precision)
+        W = self._weights()  # carries self.precision (a per-call field: no global switch)
         ws, need = self._workspace(R, S, V, dev)
         out = torch.empty((R, 3 + S), device=dev)
         depth = torch.empty((R,), device=dev) if z_vals is not None else None

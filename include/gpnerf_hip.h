@@ -12,7 +12,13 @@
  *   - `stream` is a hipStream_t (0 = default stream); every call only enqueues work;
  *   - no entry point allocates, frees or synchronises; workspaces are passed in by the caller;
  *   - return value: 0 on success, negative GPN_E_* on error (gpn_last_error() has the text);
- *   - N = R*S points in ray-major order (point n = r*S + s), V source views.
+ *   - N = R*S points in ray-major order (point n = r*S + s), V source views; N and N*V must fit a
+ *     32-bit int (checked: GPN_E_ARG otherwise);
+ *   - stateless and re-entrant: no entry point reads or writes process-global state (ABI 2: the
+ *     arithmetic mode is an argument / a field of gpn_gnt_weights_t, not a global switch).  Calls
+ *     that share an output tensor or a workspace must of course be ordered by the caller (same
+ *     stream, or events).  The measurement hooks at the end of this header are the one exception:
+ *     one timing session per process at a time (serialised by a mutex).
  */
 #ifndef GPNERF_HIP_H
 #define GPNERF_HIP_H
@@ -24,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GPN_ABI_VERSION 1
+#define GPN_ABI_VERSION 2
 #define GPN_OK 0
 #define GPN_E_ARG (-1)     /* invalid argument (shape / null pointer / unsupported size) */
 #define GPN_E_LAUNCH (-2)  /* HIP reported an error at launch */
@@ -38,6 +44,17 @@ extern "C" {
 #define GPN_MAX_SAMPLES 128
 
 typedef void* gpn_stream_t;
+
+/* Arithmetic mode of the GNT linear layers (no counterpart in the reference, which is plain fp32);
+ * an argument of gpn_rgbfeat / gpn_view_attn / gpn_ff / gpn_qpos / gpn_ray_attn and the `precision`
+ * field of the weight struct gpn_gnt_forward takes.  (ABI 1 had a process-global switch instead.)
+ *   GPN_PREC_FP32   v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation.
+ *   GPN_PREC_BF16X3 every fp32 operand is split into two bf16 pieces (hi + mid) and a product is
+ *                   w_mid*x_hi + w_hi*x_mid + w_hi*x_hi on v_mfma_f32_16x16x32_bf16 with fp32
+ *                   accumulation: ~2^-16 relative error per product, 5.3x the MFMA rate.
+ *                   Softmax, LayerNorm, residuals, the projector and the semantic pass stay fp32. */
+#define GPN_PREC_FP32 0
+#define GPN_PREC_BF16X3 1
 
 int gpn_abi_version(void);
 const char* gpn_last_error(void); /* thread-local, valid until the next failing call */
@@ -154,6 +171,8 @@ typedef struct {                 /* Transformer + Attention('qk'), transformer_n
 typedef struct {                 /* GNT, transformer_network.py:221-294 (state-dict contract a10) */
   int trans_depth;               /* <= GPN_MAX_DEPTH */
   int in_feat_ch;                /* 32 -> rgb_feat has 3+32 channels */
+  int precision;                 /* GPN_PREC_*: arithmetic mode gpn_gnt_forward runs this net in */
+  int reserved_;                 /* keeps the pointers 8-byte aligned; set to 0 */
   gpn_linear_t rgbfeat0, rgbfeat2;
   gpn_view_layer_t view[GPN_MAX_DEPTH];  /* view_crosstrans.i */
   gpn_ray_layer_t ray[GPN_MAX_DEPTH];    /* view_selftrans.i  */
@@ -186,7 +205,7 @@ int gpn_posenc(const float* pts, const float* ray_d, int R, int S, float* emb_pt
  * over ALL views either way, as in the reference. */
 int gpn_rgbfeat(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* rgb_feat, int N,
                 int V, int in_ch, int in_ld, const float* mask, float* feat, float* q0,
-                gpn_stream_t stream);
+                int precision, gpn_stream_t stream);
 
 /* Attention part of Transformer2D (attn_norm, Attention2D, residual), transformer_network.py:74-88
  * and :107-112.  q_in [N,C], feat [N,V,C], ray_diff [N,V,4], mask [N,V] -> q_out [N,C];
@@ -205,7 +224,7 @@ int gpn_rgbfeat(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* r
 int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const float* feat,
                   const float* ray_diff, const float* mask, const int32_t* perm, int N, int V,
                   float* q_out, float* hidden, int hidden_ld, float* stats, int stats_ld,
-                  gpn_stream_t stream);
+                  int precision, gpn_stream_t stream);
 
 /* No counterpart in the reference (weight preprocessing for gpn_view_attn, once per model): folds the
  * linear chains of Attention2D that have no nonlinearity in between,
@@ -228,12 +247,13 @@ int gpn_vis_order(const float* mask, int N, int V, int32_t* perm, void* scratch,
 
 /* x + FeedForward(LayerNorm(x)), transformer_network.py:114-117 / :210-213 (eps 1e-6). x [N,C]. */
 int gpn_ff(const float* norm_w, const float* norm_b, const gpn_linear_t* fc1,
-           const gpn_linear_t* fc2, const float* x_in, int N, float* x_out, gpn_stream_t stream);
+           const gpn_linear_t* fc2, const float* x_in, int N, float* x_out, int precision,
+           gpn_stream_t stream);
 
 /* q_fcs[i] on cat(q, pos-enc, view-enc), transformer_network.py:322-324. q [N,C], emb_pt [N,64],
  * emb_ray [N/S,64] (gpn_posenc); point n belongs to ray n / S. */
 int gpn_qpos(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* q_in, const float* emb_pt,
-             const float* emb_ray, int N, int S, float* q_out, gpn_stream_t stream);
+             const float* emb_ray, int N, int S, float* q_out, int precision, gpn_stream_t stream);
 
 /* Attention part of the ray Transformer, transformer_network.py:149-178 and :203-208.
  * x_in [R,S,C] -> x_out [R,S,C]; abar = mean over queries of A per head (may be NULL): the 4 head
@@ -241,7 +261,7 @@ int gpn_qpos(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const float* q_in
  * weights [R,S] = head-mean of attention row 0 (transformer_network.py:216; may be NULL).
  * 1 <= S <= GPN_MAX_SAMPLES (any S; multiples of 16 waste no lanes). */
 int gpn_ray_attn(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,
-                 float* abar, int abar_ld, float* weights, gpn_stream_t stream);
+                 float* abar, int abar_ld, float* weights, int precision, gpn_stream_t stream);
 
 typedef struct {
   int R, S, V, depth;
@@ -287,26 +307,15 @@ int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat, int rgb_f
                     int R, int S, int V, gpn_sem_args_t* sem, float* out, float* depth,
                     float* sem_feat, void* workspace, size_t workspace_bytes, gpn_stream_t stream);
 
-/* ------------------------------------------------------------------ arithmetic mode of the GNT linear layers
- * No counterpart in the reference (which is plain fp32).  Process-global, not thread-safe; read at
- * launch time by gpn_rgbfeat / gpn_view_attn / gpn_ff / gpn_qpos / gpn_ray_attn.
- *   GPN_PREC_FP32   v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation (default).
- *   GPN_PREC_BF16X3 every fp32 operand is split into two bf16 pieces (hi + mid) and a product is
- *                   w_mid*x_hi + w_hi*x_mid + w_hi*x_hi on v_mfma_f32_16x16x32_bf16 with fp32
- *                   accumulation: ~2^-16 relative error per product, 5.3x the MFMA rate.
- *                   Softmax, LayerNorm, residuals, the projector and the semantic pass stay fp32. */
-#define GPN_PREC_FP32 0
-#define GPN_PREC_BF16X3 1
-int gpn_set_precision(int mode);
-int gpn_get_precision(void);
-
 /* ------------------------------------------------------------------ measurement hooks
  * No counterpart in the reference: bench.py uses these to time individual kernels with HIP events on
  * the stream they are launched on, inside the timed region.  gpn_timing_begin creates `max_records`
  * event pairs (outside any launch path); while enabled, every launch of a stage selected in
  * `stage_mask` (bit i = stage i) is bracketed by an event pair; gpn_timing_end waits for the
  * events, returns per-stage summed milliseconds and launch counts (arrays of GPN_NSTAGES) and
- * releases the pool.  Not thread-safe; one session at a time. */
+ * releases the pool.  One session per process at a time (a second gpn_timing_begin fails until the
+ * first session has ended); the pool itself is guarded by a mutex, so launches from other threads
+ * while a session is open are safe (they are recorded if their stage is selected). */
 enum {
   GPN_ST_SAMPLE = 0, GPN_ST_PROJECT, GPN_ST_PROJECT_DEEP, GPN_ST_POSENC, GPN_ST_RGBFEAT,
   GPN_ST_VIEW_ATTN, GPN_ST_FF, GPN_ST_QPOS, GPN_ST_RAY_ATTN, GPN_ST_SEM, GPN_ST_HEADS,

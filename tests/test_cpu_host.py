@@ -25,7 +25,7 @@ def test_cabi_exports_every_declared_symbol():
     missing = [n for n in sorted(declared) if not hasattr(h, n)]
     assert not missing, "declared in include/gpnerf_hip.h but not exported: %s" % missing
     assert set(_lib.EXPORTS) == declared, "ctypes bindings out of sync with the header"
-    assert _lib.lib().gpn_abi_version() == 1
+    assert _lib.lib().gpn_abi_version() == 2
 
 
 def test_ctypes_struct_layout_matches_header_sizes():
@@ -53,16 +53,26 @@ def test_argument_errors_come_back_as_messages():
     L = _lib.lib()
     rc = L.gpn_sample_along_ray(None, None, 1.0, 2.0, 4, 8, 0, None, None, None, None)
     assert rc == -1 and b"null pointer" in L.gpn_last_error()
-    rc = L.gpn_ray_attn(None, None, 0, 48, None, None, 4, None, None)
+    rc = L.gpn_ray_attn(None, None, 0, 48, None, None, 4, None, 0, None)
     assert rc == 0  # empty batch is a no-op
     # argument checks run before any HIP call, so they are testable without a GPU
     assert L.gpn_view_fold(None, None, None) == -1 and b"null pointer" in L.gpn_last_error()
-    assert L.gpn_view_attn(None, None, None, None, None, None, 16, 10, None, None, 8, None, 64, None) == -1
+    assert L.gpn_view_attn(None, None, None, None, None, None, 16, 10, None, None, 8, None, 64, 1, None) == -1
     assert b"null pointer" in L.gpn_last_error()
-    assert L.gpn_get_precision() in (0, 1)
-    before = L.gpn_get_precision()
-    assert L.gpn_set_precision(7) == -1 and b"unknown mode" in L.gpn_last_error()
-    assert L.gpn_get_precision() == before
+    # ABI 2: the arithmetic mode is an argument (no process-global switch); unknown modes are refused
+    assert not hasattr(L, "gpn_set_precision")
+    assert L.gpn_ff(None, None, None, None, None, 16, None, 7, None) == -1
+    assert b"unknown precision 7" in L.gpn_last_error()
+    with pytest.raises(ValueError):
+        _lib.precision_code("fp16")
+    # N = R*S (and N*V) must fit a 32-bit int: refused instead of wrapping into a bad grid
+    W = _lib.GntWeights()
+    for lin in (W.ray[0].q, W.ray[0].k, W.ray[0].v, W.ray[0].out):
+        lin.w = 16  # non-null, aligned: the call must stop at the range check, before any launch
+    W.ray[0].attn_norm_w = W.ray[0].attn_norm_b = 16
+    assert L.gpn_ray_attn(ctypes.byref(W.ray[0]), ctypes.c_void_p(16), 1 << 26, 128, ctypes.c_void_p(16),
+                          None, 4, None, 0, None) == -1
+    assert b"does not fit a 32-bit int" in L.gpn_last_error()
     assert L.gpn_gnt_workspace_bytes(4096, 64, 10, 8) > 4096 * 64 * 10 * (8 * 8 + 64) * 4  # hidden side channel + feat
     assert L.gpn_gnt_workspace_bytes(0, 0, 0, 0) == 0
     with pytest.raises(RuntimeError, match="gpn_sample_along_ray failed"):

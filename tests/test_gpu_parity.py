@@ -40,12 +40,9 @@ def net(dev):
 def prec(request, net):
     """Arithmetic mode of the GNT linear layers: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs per
     product, fp32 accumulate).  Both modes are held to the same end-to-end bar (TOL)."""
-    from gp_nerf_amd import _lib
     net.precision = request.param
-    _lib.set_precision(request.param)
     yield request.param
     net.precision = "fp32"
-    _lib.set_precision("fp32")
 
 
 # per-kernel bound (inputs taken from the oracle's intermediates, one kernel at a time)
@@ -90,11 +87,6 @@ def rel(a, b):
     assert a.shape == b.shape, (a.shape, b.shape)
     assert np.isfinite(a).all(), "non-finite values in the HIP result"
     return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
-
-
-def _lib_reset_precision():
-    from gp_nerf_amd import _lib
-    _lib.set_precision("fp32")
 
 
 def to(dev, d):
@@ -290,6 +282,7 @@ def _stage_inputs(S, R=8):
 def test_gnt_stages(dev, net, prec, S):
     from gp_nerf_amd import _lib
     L = _lib.lib()
+    pc = _lib.precision_code(prec)
     c, rec, _ = _stage_inputs(S)
     R, V = c["rgb_feat"].shape[0], c["rgb_feat"].shape[2]
     N = R * S
@@ -311,7 +304,7 @@ def test_gnt_stages(dev, net, prec, S):
     # rgbfeat
     feat, q0 = e(N, V, 64), e(N, 64)
     _lib.check(L.gpn_rgbfeat(C.byref(W.rgbfeat0), C.byref(W.rgbfeat2), _lib.ptr(rgbf_d), N, V,
-                             35, 0, None, _lib.ptr(feat), _lib.ptr(q0), st), "rgbfeat")
+                             35, 0, None, _lib.ptr(feat), _lib.ptr(q0), pc, st), "rgbfeat")
     errs["feat"] = rel(dec_feat(feat, prec), rec["feat"].reshape(N, V, 64))
     errs["q0"] = rel(q0, rec["q0"].reshape(N, 64))
     rd, mk = f(c["ray_diff"]), f(c["mask"])
@@ -321,7 +314,7 @@ def test_gnt_stages(dev, net, prec, S):
     rgbf36[..., :35] = rgbf_d.reshape(N, V, 35)
     feat_m, q0_m = torch.full((N, V, 64), float("nan"), device=dev), e(N, 64)
     _lib.check(L.gpn_rgbfeat(C.byref(W.rgbfeat0), C.byref(W.rgbfeat2), _lib.ptr(rgbf36), N, V,
-                             35, 36, _lib.ptr(mk), _lib.ptr(feat_m), _lib.ptr(q0_m), st), "rgbfeat-masked")
+                             35, 36, _lib.ptr(mk), _lib.ptr(feat_m), _lib.ptr(q0_m), pc, st), "rgbfeat-masked")
     vis_nv = mk.reshape(N, V) != 0
     stored = vis_nv | ~vis_nv.any(dim=1, keepdim=True)
     assert torch.equal(q0_m, q0), "padded rows / masked stores changed q0"
@@ -335,7 +328,7 @@ def test_gnt_stages(dev, net, prec, S):
         qo, hd, stt = e(N, 64), torch.zeros(N, V, 8, device=dev), e(N, 64)
         _lib.check(L.gpn_view_attn(C.byref(W.view[l]), _lib.ptr(q_in), _lib.ptr(feat_ref), _lib.ptr(rd),
                                    _lib.ptr(mk), None, N, V, _lib.ptr(qo), _lib.ptr(hd), 8,
-                                   _lib.ptr(stt), 64, st), "view")
+                                   _lib.ptr(stt), 64, pc, st), "view")
         errs["view_attn%d" % l] = rel(qo, rec["q_view_attn"][l].reshape(N, 64))
         if l == 0:  # the same layer without the folded weight products (reference operation order)
             plain = type(W.view[l])()
@@ -343,7 +336,7 @@ def test_gnt_stages(dev, net, prec, S):
             plain.folded = None
             qo_p = e(N, 64)
             _lib.check(L.gpn_view_attn(C.byref(plain), _lib.ptr(q_in), _lib.ptr(feat_ref), _lib.ptr(rd),
-                                       _lib.ptr(mk), None, N, V, _lib.ptr(qo_p), None, 64, None, 64, st),
+                                       _lib.ptr(mk), None, N, V, _lib.ptr(qo_p), None, 64, None, 64, pc, st),
                        "view-unfolded")
             errs["view_attn_unfolded"] = rel(qo_p, rec["q_view_attn"][l].reshape(N, 64))
         if l == 0:  # rows gpn_rgbfeat leaves unstored (NaN here) must not reach the result
@@ -351,7 +344,7 @@ def test_gnt_stages(dev, net, prec, S):
             feat_nan[~stored] = float("nan")
             qo_n = e(N, 64)
             _lib.check(L.gpn_view_attn(C.byref(W.view[l]), _lib.ptr(q_in), _lib.ptr(feat_nan), _lib.ptr(rd),
-                                       _lib.ptr(mk), None, N, V, _lib.ptr(qo_n), None, 8, None, 64, st),
+                                       _lib.ptr(mk), None, N, V, _lib.ptr(qo_n), None, 8, None, 64, pc, st),
                        "view-unstored-rows")
             assert torch.equal(qo_n, qo), "an unstored feature row changed the view attention"
         # same launch in visibility-sorted order: bit-identical outputs
@@ -370,7 +363,7 @@ def test_gnt_stages(dev, net, prec, S):
         # (entries of masked pairs are never written: they stay 0 on both sides)
         _lib.check(L.gpn_view_attn(C.byref(W.view[l]), _lib.ptr(q_in), _lib.ptr(feat_ref), _lib.ptr(rd),
                                    _lib.ptr(mk), _lib.ptr(perm2), N, V, _lib.ptr(qo2), _lib.ptr(hd2), 8,
-                                   _lib.ptr(stt2), 64, st), "view-perm")
+                                   _lib.ptr(stt2), 64, pc, st), "view-perm")
         assert torch.equal(qo, qo2) and torch.equal(stt, stt2) and torch.equal(hd, hd2), \
             "visibility-sorted order changed the results"
         assert bool((hd[(mk.reshape(N, V) == 0)] == 0).all()), "a masked pair's hidden row was written"
@@ -385,13 +378,13 @@ def test_gnt_stages(dev, net, prec, S):
         q2 = e(N, 64)
         ff_in = f(rec["q_view_attn"][l].reshape(N, 64))
         _lib.check(L.gpn_ff(vl.ff_norm_w, vl.ff_norm_b, C.byref(vl.ff1), C.byref(vl.ff2),
-                            _lib.ptr(ff_in), N, _lib.ptr(q2), st), "ff")
+                            _lib.ptr(ff_in), N, _lib.ptr(q2), pc, st), "ff")
         errs["view_ff%d" % l] = rel(q2, rec["q_view"][l].reshape(N, 64))
         if l % 2 == 0:
             q3 = e(N, 64)
             qp_in = f(rec["q_view"][l].reshape(N, 64))
             _lib.check(L.gpn_qpos(C.byref(W.qfc0[l]), C.byref(W.qfc2[l]), _lib.ptr(qp_in),
-                                  _lib.ptr(emb_ref_pt), _lib.ptr(emb_ref_ray), N, S, _lib.ptr(q3), st), "qpos")
+                                  _lib.ptr(emb_ref_pt), _lib.ptr(emb_ref_ray), N, S, _lib.ptr(q3), pc, st), "qpos")
             errs["qpos%d" % l] = rel(q3, rec["q_pos"][l // 2].reshape(N, 64))
             x_in = rec["q_pos"][l // 2]
         else:
@@ -399,7 +392,7 @@ def test_gnt_stages(dev, net, prec, S):
         xo, ab, wt = e(R, S, 64), torch.full((R, S, 6), -7.0, device=dev), e(R, S)
         x_in_d = f(x_in)
         _lib.check(L.gpn_ray_attn(C.byref(W.ray[l]), _lib.ptr(x_in_d), R, S, _lib.ptr(xo), _lib.ptr(ab),
-                                  6, _lib.ptr(wt), st), "ray")  # abar rows with leading dimension 6
+                                  6, _lib.ptr(wt), pc, st), "ray")  # abar rows with leading dimension 6
         errs["ray_attn%d" % l] = rel(xo, rec["q_ray_attn"][l])
         errs["abar%d" % l] = rel(ab[:, :, :4], rec["A"][l].mean(dim=2).permute(0, 2, 1))
         assert bool((ab[:, :, 4:] == -7.0).all()), "gpn_ray_attn wrote outside its 4 abar columns"
@@ -455,6 +448,7 @@ def test_ray_attn_large_scores(dev, prec):
     big.precision = prec
     W = big._weights()
     L, st = _lib.lib(), _lib.stream()
+    pc = _lib.precision_code(prec)
     R, S = 37, 40
     x = torch.randn(R, S, 64, generator=torch.Generator().manual_seed(11)) * 1.5
     _, A, mid = oracle.gnt.ray_transformer(sd, "view_selftrans.0", x)
@@ -463,7 +457,7 @@ def test_ray_attn_large_scores(dev, prec):
     xd = x.to(dev).contiguous()
     xo, ab, wt = torch.empty(R, S, 64, device=dev), torch.empty(R, S, 4, device=dev), torch.empty(R, S, device=dev)
     _lib.check(L.gpn_ray_attn(C.byref(W.ray[0]), _lib.ptr(xd), R, S, _lib.ptr(xo), _lib.ptr(ab), 4,
-                              _lib.ptr(wt), st), "ray-large")
+                              _lib.ptr(wt), pc, st), "ray-large")
     torch.cuda.synchronize()
     tol = 5e-3 if prec == "bf16x3" else 1e-4
     errs = {"x": rel(xo, mid), "abar": rel(ab, A.mean(dim=2).permute(0, 2, 1)),
@@ -480,6 +474,7 @@ def test_gnt_stages_many_tiles(dev, net, prec):
     import torch.nn.functional as F
     from gp_nerf_amd import _lib
     L = _lib.lib()
+    pc = _lib.precision_code(prec)
     sd = cases.weights()
     R, S, V = 1100, 64, 10
     N = R * S
@@ -515,7 +510,7 @@ def test_gnt_stages_many_tiles(dev, net, prec):
         qo, hd, stt = e(N, 64), torch.zeros(N, V, 8, device=dev), e(N, 64)
         _lib.check(L.gpn_view_attn(C.byref(W.view[0]), _lib.ptr(qd), _lib.ptr(fd), _lib.ptr(rd), _lib.ptr(mk),
                                    _lib.ptr(pm) if pm is not None else None, N, V, _lib.ptr(qo),
-                                   _lib.ptr(hd), 8, _lib.ptr(stt), 64, st), "view")
+                                   _lib.ptr(hd), 8, _lib.ptr(stt), 64, pc, st), "view")
         outs.append((qo, hd, stt))
     assert all(torch.equal(a_, b_) for a_, b_ in zip(*outs)), "visibility-sorted order changed the results"
     qo, hd, stt = outs[0]
@@ -530,14 +525,14 @@ def test_gnt_stages_many_tiles(dev, net, prec):
     out = e(N, 64)
     vl = W.view[0]
     _lib.check(L.gpn_ff(vl.ff_norm_w, vl.ff_norm_b, C.byref(vl.ff1), C.byref(vl.ff2), _lib.ptr(qd), N,
-                        _lib.ptr(out), st), "ff")
+                        _lib.ptr(out), pc, st), "ff")
     errs["ff"] = rel(out, want.reshape(N, 64))
     # rgbfeat
     want = oracle.gnt._lin(sd, "rgbfeat_fc.2", F.relu(oracle.gnt._lin(sd, "rgbfeat_fc.0", rgbf)))
     fo, q0 = e(N, V, 64), e(N, 64)
     rgbf_d = f(rgbf.reshape(N, V, 35))
     _lib.check(L.gpn_rgbfeat(C.byref(W.rgbfeat0), C.byref(W.rgbfeat2), _lib.ptr(rgbf_d), N, V, 35, 0,
-                             None, _lib.ptr(fo), _lib.ptr(q0), st), "rgbfeat")
+                             None, _lib.ptr(fo), _lib.ptr(q0), pc, st), "rgbfeat")
     errs["feat"] = rel(dec_feat(fo, prec), want.reshape(N, V, 64))
     errs["q0"] = rel(q0, want.max(dim=2)[0].reshape(N, 64))
     # padded rows + masked stores over many tiles per wave: same bits wherever a row is stored
@@ -545,7 +540,7 @@ def test_gnt_stages_many_tiles(dev, net, prec):
     rgbf36[..., :35] = rgbf_d
     fo_m, q0_m = torch.full((N, V, 64), float("nan"), device=dev), e(N, 64)
     _lib.check(L.gpn_rgbfeat(C.byref(W.rgbfeat0), C.byref(W.rgbfeat2), _lib.ptr(rgbf36), N, V, 35, 36,
-                             _lib.ptr(mk), _lib.ptr(fo_m), _lib.ptr(q0_m), st), "rgbfeat-masked")
+                             _lib.ptr(mk), _lib.ptr(fo_m), _lib.ptr(q0_m), pc, st), "rgbfeat-masked")
     vis_nv = mk != 0
     stored = vis_nv | ~vis_nv.any(dim=1, keepdim=True)
     assert torch.equal(q0_m, q0) and torch.equal(fo_m[stored].view(torch.int32), fo[stored].view(torch.int32))
@@ -554,14 +549,14 @@ def test_gnt_stages_many_tiles(dev, net, prec):
     fd_nan[~stored] = float("nan")
     qo_n = e(N, 64)
     _lib.check(L.gpn_view_attn(C.byref(W.view[0]), _lib.ptr(qd), _lib.ptr(fd_nan), _lib.ptr(rd), _lib.ptr(mk),
-                               _lib.ptr(perm2), N, V, _lib.ptr(qo_n), None, 8, None, 64, st), "view-unstored")
+                               _lib.ptr(perm2), N, V, _lib.ptr(qo_n), None, 8, None, 64, pc, st), "view-unstored")
     assert torch.equal(qo_n, qo), "an unstored feature row changed the view attention"
     # q positional MLP (layer 0)
     xin = torch.cat([q.reshape(N, 64), emb[:, :126]], -1)
     want = oracle.gnt._lin(sd, "q_fcs.0.2", F.relu(oracle.gnt._lin(sd, "q_fcs.0.0", xin)))
     out, emb_p, emb_r = e(N, 64), f(emb[:, :64]), f(emb.reshape(R, S, 128)[:, 0, 64:])
     _lib.check(L.gpn_qpos(C.byref(W.qfc0[0]), C.byref(W.qfc2[0]), _lib.ptr(qd), _lib.ptr(emb_p),
-                          _lib.ptr(emb_r), N, S, _lib.ptr(out), st), "qpos")
+                          _lib.ptr(emb_r), N, S, _lib.ptr(out), pc, st), "qpos")
     errs["qpos"] = rel(out, want)
     # ray attention (layer 0)
     pr = "view_selftrans.0"
@@ -569,7 +564,7 @@ def test_gnt_stages_many_tiles(dev, net, prec):
     xo, ab, wt = e(R, S, 64), e(R, S, 4), e(R, S)
     q3 = f(q)
     _lib.check(L.gpn_ray_attn(C.byref(W.ray[0]), _lib.ptr(q3), R, S, _lib.ptr(xo), _lib.ptr(ab), 4,
-                              _lib.ptr(wt), st), "ray")
+                              _lib.ptr(wt), pc, st), "ray")
     errs["ray_attn"] = rel(xo, o + q)
     errs["abar"] = rel(ab, A.mean(dim=2).permute(0, 2, 1))
     errs["weights"] = rel(wt, A.mean(dim=1)[:, 0])
@@ -732,7 +727,6 @@ def test_full_size_properties(dev):
         for k in ("rgb", "depth", "weights"):
             assert torch.equal(twice[lvl][k].view(torch.int32), full[lvl][k].view(torch.int32)), (lvl, k)
         assert torch.equal(twice[lvl]["feats_out_3d"], full[lvl]["feats_out_3d"] * 2.0), lvl
-    _lib_reset_precision()
 
 
 def test_ray_sampler_bit_exact(dev, golden):
@@ -841,7 +835,7 @@ def test_encoders_vs_golden_and_nhwc_handoff(dev, golden):
     proj = Projector(dev)
     args_ = (pts.contiguous(), rb["camera"], rb["src_rgbs"], rb["src_cameras"])
     a = proj.compute(*args_, coarse, deep)
-    assert proj._nhwc(deep).data_ptr() == deep.data_ptr()
+    assert proj._nhwc(deep, "deep").data_ptr() == deep.data_ptr()
     b = proj.compute(*args_, coarse.contiguous(), deep.contiguous())  # NCHW copies -> repack kernel
     for x, y in zip(a, b):
         assert torch.equal(x, y)

@@ -7,18 +7,17 @@ from gp_nerf_amd.transformer_network import GNT
 dev = torch.device("cuda:0")
 args = types.SimpleNamespace(netwidth=64, trans_depth=8, save_feature=False, semantic_model="fpn", num_classes=20)
 net = GNT(args, 32, 63, 63, ret_alpha=True); net.load_state_dict(synth.gnt_state_dict()); net = net.to(dev).eval()
-_lib.set_precision("bf16x3")
+net.precision = "bf16x3"; PC = 1
 W = net._weights(); st = _lib.stream()
 for path in sys.argv[1:]:
     L = C.CDLL(path)
     for name, (res, at) in _lib._SIGS.items():
         if hasattr(L, name):
             getattr(L, name).restype, getattr(L, name).argtypes = res, at
-    L.gpn_set_precision(1)
     for N in [int(v) for v in os.environ.get('FF_NS', '196608,262144').split(',')]:
         q = torch.randn(N, 64, device=dev); qo = torch.empty_like(q)
         vl = W.view[0]
-        fn = lambda: L.gpn_ff(vl.ff_norm_w, vl.ff_norm_b, C.byref(vl.ff1), C.byref(vl.ff2), _lib.ptr(q), N, _lib.ptr(qo), st)
+        fn = lambda: L.gpn_ff(vl.ff_norm_w, vl.ff_norm_b, C.byref(vl.ff1), C.byref(vl.ff2), _lib.ptr(q), N, _lib.ptr(qo), PC, st)
         for _ in range(20): fn()
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

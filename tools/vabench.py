@@ -16,7 +16,7 @@ from gp_nerf_amd import render_ray as rr
 dev = torch.device("cuda:0")
 scene, net, projector = bench.build(dev)
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
-_lib.set_precision(prec)
+net.precision = prec; PC = _lib.precision_code(prec)
 W = net._weights()
 L = _lib.lib()
 st = _lib.stream()
@@ -32,7 +32,7 @@ feat = torch.empty(N, V, 64, device=dev)
 q = torch.empty(N, 64, device=dev)
 rgb_feat = rgb_feat.reshape(N, V, -1).contiguous()
 _lib.check(L.gpn_rgbfeat(C.byref(W.rgbfeat0), C.byref(W.rgbfeat2), _lib.ptr(rgb_feat), N, V, 35, rgb_feat.shape[-1],
-                         None, _lib.ptr(feat), _lib.ptr(q), st), "rgbfeat")
+                         None, _lib.ptr(feat), _lib.ptr(q), PC, st), "rgbfeat")
 qo = torch.empty_like(q)
 logits = torch.empty(N, V, 8, 8, device=dev)  # hidden side channel [N,V,depth,8]
 stats = torch.empty(N, 8, 64, device=dev)
@@ -62,7 +62,7 @@ def run(m, use_perm, side, ld=8 * 64, hld=8 * 8):
     lg = _lib.ptr(logits) if side else None
     sp = _lib.ptr(stats) if side else None
     return timeit(lambda: _lib.check(L.gpn_view_attn(C.byref(vl), _lib.ptr(q), _lib.ptr(feat), _lib.ptr(ray_diff),
-                                                     _lib.ptr(m), p, N, V, _lib.ptr(qo), lg, hld, sp, ld, st), "va"))
+                                                     _lib.ptr(m), p, N, V, _lib.ptr(qo), lg, hld, sp, ld, PC, st), "va"))
 
 
 ones = torch.ones_like(mask)

@@ -50,12 +50,18 @@ def _strided_hw(ray_sampler, render_stride):
 
 
 _PINNED = {}  # (level, key) -> pinned host buffer reused across images (page-locked D2H runs at PCIe speed)
+# Buffers above this size are not kept between images (feats_out_3d of a 640x480 image is ~70 GB: it
+# is staged through pageable memory once rather than pinned for the life of the process).
+PINNED_KEEP_BYTES = 1 << 30
 
 
 def _to_host(t, tag):
     """One asynchronous copy into a cached page-locked buffer (the reference's per-chunk `.cpu()` into
     pageable memory, render_image.py:78-85, costs more than the rendering of a small image).  The
     returned CPU tensor is a fresh clone, so results of successive images do not alias."""
+    nbytes = t.numel() * t.element_size()
+    if nbytes > PINNED_KEEP_BYTES:
+        return t.cpu(), None, False  # synchronous copy into a fresh pageable tensor; nothing retained
     buf = _PINNED.get(tag)
     if buf is None or buf.numel() < t.numel() or buf.dtype != t.dtype:
         buf = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
@@ -64,7 +70,7 @@ def _to_host(t, tag):
     view.copy_(t, non_blocking=True)
     done = torch.cuda.Event()
     done.record()
-    return view, done
+    return view, done, True
 
 
 def _merge(acc, Hs, Ws):
@@ -77,13 +83,13 @@ def _merge(acc, Hs, Ws):
             if k == "random_sigma":
                 continue
             cat = torch.cat(acc[lvl][k], dim=0)
-            staged.append((lvl, k) + (_to_host(cat, (lvl, k)) if cat.is_cuda else (cat, None)))
+            staged.append((lvl, k) + (_to_host(cat, (lvl, k)) if cat.is_cuda else (cat, None, False)))
     # every copy has been queued; each output is cloned out of its page-locked buffer as soon as ITS
     # copy has landed, while the later ones are still in flight (the clones cost more than the copies)
-    for lvl, k, host, done in staged:
+    for lvl, k, host, done, shared in staged:
         if done is not None:
             done.synchronize()
-        cat = host.clone()
+        cat = host.clone() if shared else host
         if k == "feats_out":
             acc[lvl][k] = cat.reshape((Hs, Ws, 512, -1)).squeeze()
         else:
@@ -128,21 +134,53 @@ def shard_rows(Hs, world_size):
 
 
 GATHER_KEYS = ("rgb", "depth", "feats_out")
+_KEY_WIDTH = {"rgb": 3, "depth": 1, "feats_out": 512}
+
+
+def tile_layout(N_samples, N_importance, ret_alpha, has_semantics, gather_weights):
+    """Columns of the all-gathered tile per output level, derived from the call's ARGUMENTS only --
+    every rank must agree on them, including a rank that owns no rows and therefore renders nothing.
+    -> {level: [(key, width), ...] or None (level absent)}."""
+    out = OrderedDict()
+    for lvl in ("outputs_coarse", "outputs_fine"):
+        fine = lvl == "outputs_fine"
+        if fine and N_importance <= 0:
+            out[lvl] = None
+            continue
+        with_alpha = fine or ret_alpha  # the fine pass always runs with ret_alpha (reference render_ray.py:290)
+        cols = [("rgb", 3)]
+        if with_alpha:
+            cols.append(("depth", 1))
+        if has_semantics:
+            cols.append(("feats_out", 512))
+        if gather_weights and with_alpha:
+            cols.append(("weights", N_samples + (N_importance if fine else 0)))
+        out[lvl] = cols
+    return out
 
 
 def render_image_sharded(ray_sampler, ray_batch, model, projector, chunk_size, N_samples,
                          inv_uniform=False, N_importance=0, det=False, white_bkgd=False,
                          render_stride=1, featmaps=None, deep_semantics=None, ret_alpha=False,
-                         single_net=False, group=None, gather_weights=False, render_fn=None):
+                         single_net=False, group=None, gather_weights=False, render_fn=None,
+                         sem_head=None, labels_only=False):
     """Multi-GPU render_single_image: rank k renders rows [k*rows, (k+1)*rows) of the strided grid
     (source maps, cameras and weights replicated), then one all_gather_into_tensor per output level
     moves rgb[3] + depth[1] + feats_out[512] (+ weights[S]) per ray.  feats_out_3d is never
     gathered.  Returns device tensors shaped like render_single_image's outputs on every rank.
+    A rank whose row block is empty (H' < world size) renders nothing and contributes a zero tile.
+
+    sem_head (a NeRFSemSegFPNHead on this rank's device): adds 'labels' (uint8 [2h,2w], the label
+    image of the head's logits: reference eval_gpnerf.py:201-206 + loss.py:296) to every level.
+    With labels_only=True the 2 KB/ray feature tiles do not go to every rank: they are gathered to
+    rank 0 only, rank 0 runs the head (its GroupNorm needs the whole image) and the 1 B/pixel label
+    image is broadcast; rgb / depth are still all-gathered; 'feats_out' is then present on rank 0 only.
     `render_fn` (tests only) replaces the per-rank chunk renderer."""
     import torch.distributed as dist
 
-    G = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    multi = dist.is_initialized()
+    G = dist.get_world_size(group) if multi else 1
+    rank = dist.get_rank(group) if multi else 0
     Hs, Ws = _strided_hw(ray_sampler, render_stride)
     rows, parts = shard_rows(Hs, G)
     r0, r1 = parts[rank]
@@ -150,26 +188,33 @@ def render_image_sharded(ray_sampler, ray_batch, model, projector, chunk_size, N
     acc = fn(ray_batch, model, projector, chunk_size, N_samples, inv_uniform, N_importance, det,
              white_bkgd, featmaps, deep_semantics, ret_alpha, single_net, r0 * Ws, r1 * Ws, False)
     dev = ray_batch["ray_o"].device
+    layout = tile_layout(N_samples, N_importance, ret_alpha, deep_semantics is not None, gather_weights)
+    if labels_only and sem_head is None:
+        raise ValueError("labels_only=True needs a sem_head")
     out = OrderedDict()
-    for lvl in ("outputs_coarse", "outputs_fine"):
-        if acc[lvl] is None:
+    for lvl, cols in layout.items():
+        if cols is None:
             out[lvl] = None
             continue
-        keys = [k for k in GATHER_KEYS if k in acc[lvl]]
-        if gather_weights and "weights" in acc[lvl]:
-            keys.append("weights")
-        cols = []
-        for k in keys:
-            t = torch.cat(acc[lvl][k], dim=0) if acc[lvl][k] else None
-            cols.append(t.reshape(t.shape[0], -1) if t is not None else None)
-        widths = [c.shape[1] for c in cols] if r1 > r0 else None
-        if widths is None:  # a rank without rows still has to know the tile width
-            widths = [3, 1, 512][:len(keys)]
-            if len(keys) > 3:
-                widths.append(N_samples + (N_importance if lvl == "outputs_fine" else 0))
-        tile = torch.zeros((rows * Ws, sum(widths)), device=dev)
-        if r1 > r0:
-            tile[: (r1 - r0) * Ws] = torch.cat(cols, dim=1)
+        # features travel separately (to rank 0 only) in labels_only mode
+        split_feats = labels_only and any(k == "feats_out" for k, _ in cols)
+        shared = [(k, w) for k, w in cols if not (split_feats and k == "feats_out")]
+
+        def build(spec):
+            tile = torch.zeros((rows * Ws, sum(w for _, w in spec)), device=dev)
+            if r1 > r0:
+                parts_ = []
+                for k, w in spec:
+                    t = torch.cat(acc[lvl][k], dim=0)
+                    t = t.reshape(t.shape[0], -1)
+                    if t.shape != ((r1 - r0) * Ws, w):
+                        raise RuntimeError("rank %d: %s/%s has shape %s, the tile layout expects [%d, %d]"
+                                           % (rank, lvl, k, tuple(t.shape), (r1 - r0) * Ws, w))
+                    parts_.append(t)
+                tile[: (r1 - r0) * Ws] = torch.cat(parts_, dim=1)
+            return tile
+
+        tile = build(shared)
         if G > 1:
             full = torch.empty((G * rows * Ws, tile.shape[1]), device=dev)
             dist.all_gather_into_tensor(full, tile, group=group)
@@ -178,7 +223,31 @@ def render_image_sharded(ray_sampler, ray_batch, model, projector, chunk_size, N
         full = full[: Hs * Ws]
         out[lvl] = OrderedDict()
         o = 0
-        for k, wdt in zip(keys, widths):
+        for k, wdt in shared:
             out[lvl][k] = full[:, o:o + wdt].reshape(Hs, Ws, wdt).squeeze()
             o += wdt
+        if split_feats:
+            ftile = build([("feats_out", 512)])
+            if G > 1:
+                bufs = [torch.empty_like(ftile) for _ in range(G)] if rank == 0 else None
+                dist.gather(ftile, bufs, dst=dist.get_global_rank(group, 0) if group is not None else 0,
+                            group=group)
+                if rank == 0:
+                    out[lvl]["feats_out"] = torch.cat(bufs, dim=0)[: Hs * Ws].reshape(Hs, Ws, 512)
+            else:
+                out[lvl]["feats_out"] = ftile[: Hs * Ws].reshape(Hs, Ws, 512)
+        if sem_head is not None and "feats_out" in dict(cols):
+            lab = None
+            if not labels_only or rank == 0:
+                feats = out[lvl]["feats_out"]
+                if render_stride == 1:  # reference eval_gpnerf.py:201-203: the head works on the half grid
+                    feats = feats[::2, ::2, :]
+                lab = sem_head.labels(feats.permute(2, 0, 1).unsqueeze(0).contiguous(), torch.uint8)
+            if labels_only and G > 1:
+                hh, ww = (len(range(0, Hs, 2)), len(range(0, Ws, 2))) if render_stride == 1 else (Hs, Ws)
+                if lab is None:
+                    lab = torch.empty((2 * hh, 2 * ww), dtype=torch.uint8, device=dev)
+                dist.broadcast(lab, src=dist.get_global_rank(group, 0) if group is not None else 0,
+                               group=group)
+            out[lvl]["labels"] = lab
     return out

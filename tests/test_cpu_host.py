@@ -149,59 +149,96 @@ def test_sem_head_oracle_shapes_and_determinism():
     assert torch.equal(out, oracle.sem_head.forward(sd, x))
 
 
-# ------------------------------------------------------------------ multi-GPU path on gloo, world 2
+# ------------------------------------------------------------------ multi-GPU path on gloo (world 2 and 4)
+N_S, N_I = 8, 3
+
+
 def _fake_render(ray_batch, model, projector, chunk_size, N_samples, inv_uniform, N_importance, det,
                  white_bkgd, featmaps, deep_semantics, ret_alpha, single_net, start, stop, f3d):
-    """Stands in for the per-rank chunk renderer: outputs are pure functions of the ray index."""
+    """Stands in for the per-rank chunk renderer: outputs are pure functions of the ray index, with the
+    structure _render_chunks returns (a rank without rays returns empty dicts; no fine level without
+    importance samples)."""
     from collections import OrderedDict
     acc = OrderedDict([("outputs_coarse", OrderedDict()), ("outputs_fine", OrderedDict())])
+    if N_importance <= 0:
+        acc["outputs_fine"] = None
     for i in range(start, stop, chunk_size):
         j = min(i + chunk_size, stop)
         idx = torch.arange(i, j, dtype=torch.float32)
-        for lvl, off in (("outputs_coarse", 0.0), ("outputs_fine", 0.5)):
+        for lvl, off, S in (("outputs_coarse", 0.0, N_samples), ("outputs_fine", 0.5, N_samples + N_importance)):
+            if acc[lvl] is None:
+                continue
             acc[lvl].setdefault("rgb", []).append(torch.stack([idx, idx + 1, idx + 2], 1) + off)
             acc[lvl].setdefault("depth", []).append(idx * 0.25 + off)
             acc[lvl].setdefault("feats_out", []).append(idx[:, None] + torch.arange(512.0)[None] + off)
-            acc[lvl].setdefault("weights", []).append(idx[:, None] * torch.ones(1, N_samples) + off)
+            acc[lvl].setdefault("weights", []).append(idx[:, None] * torch.ones(1, S) + off)
     return acc
 
 
-def _worker(rank, world, port, H, W, q):
+class _FakeHead:
+    """labels(feats [1,512,h,w]) -> uint8 [2h,2w]: a deterministic function of the whole feature image
+    (like the real head's GroupNorm, it needs all rows: the image mean enters every label)."""
+
+    def labels(self, feats, dtype):
+        m = feats.mean()
+        lab = ((feats[0, :21] - m).argmax(dim=0)).to(dtype)
+        return lab.repeat_interleave(2, 0).repeat_interleave(2, 1)
+
+
+def _worker(rank, world, port, H, W, kw, q):
     import torch.distributed as dist
     from gp_nerf_amd.render_image import render_image_sharded
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sampler = types.SimpleNamespace(H=H, W=W)
     rb = {"ray_o": torch.zeros(H * W, 3)}
-    out = render_image_sharded(sampler, rb, None, None, 50, 8, render_fn=_fake_render)
-    q.put((rank, {l: {k: v.numpy().copy() for k, v in out[l].items()} for l in out}))  # by value
+    kw = dict(kw)
+    if kw.pop("head", False):
+        kw["sem_head"] = _FakeHead()
+    out = render_image_sharded(sampler, rb, None, None, 50, N_S, render_fn=_fake_render,
+                               deep_semantics=torch.zeros(1), ret_alpha=True, **kw)
+    q.put((rank, {l: (None if out[l] is None else {k: v.numpy().copy() for k, v in out[l].items()})
+                  for l in out}))  # by value
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("H", [6, 7])  # 7 rows over 2 ranks: the last tile is padded
-def test_sharded_render_world2_gloo(H):
-    from gp_nerf_amd.render_image import render_image_sharded, shard_rows
-    W = 5
-    rows, parts = shard_rows(H, 2)
-    assert parts[0][0] == 0 and parts[-1][1] == H and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+def _run_world(world, H, W, kw):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, H, W, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, H, W, kw, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=120) for _ in range(2))
+    res = dict(q.get(timeout=180) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    # single-process result of the same fake renderer = ground truth
-    sampler = types.SimpleNamespace(H=H, W=W)
-    one = render_image_sharded(sampler, {"ray_o": torch.zeros(H * W, 3)}, None, None, 50, 8,
-                               render_fn=_fake_render)
+    return res
+
+
+def _single(H, W, kw):
+    from gp_nerf_amd.render_image import render_image_sharded
+    kw = dict(kw)
+    if kw.pop("head", False):
+        kw["sem_head"] = _FakeHead()
+    return render_image_sharded(types.SimpleNamespace(H=H, W=W), {"ray_o": torch.zeros(H * W, 3)}, None, None,
+                                50, N_S, render_fn=_fake_render, deep_semantics=torch.zeros(1),
+                                ret_alpha=True, **kw)
+
+
+@pytest.mark.parametrize("H", [6, 7])  # 7 rows over 2 ranks: the last tile is padded
+def test_sharded_render_world2_gloo(H):
+    from gp_nerf_amd.render_image import shard_rows
+    W = 5
+    rows, parts = shard_rows(H, 2)
+    assert parts[0][0] == 0 and parts[-1][1] == H and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+    kw = dict(N_importance=N_I)
+    res = _run_world(2, H, W, kw)
+    one = _single(H, W, kw)  # single-process result of the same fake renderer = ground truth
     for r in (0, 1):
         for lvl in ("outputs_coarse", "outputs_fine"):
             assert set(res[r][lvl]) == {"rgb", "depth", "feats_out"}
@@ -210,3 +247,40 @@ def test_sharded_render_world2_gloo(H):
     assert one["outputs_fine"]["rgb"].shape == (H, W, 3)
     assert one["outputs_fine"]["feats_out"].shape == (H, W, 512)
     assert float(one["outputs_coarse"]["depth"][H - 1, W - 1]) == (H * W - 1) * 0.25
+
+
+@pytest.mark.parametrize("kw", [dict(N_importance=N_I, gather_weights=True),
+                                dict(N_importance=0),
+                                dict(N_importance=N_I, head=True, labels_only=True),
+                                dict(N_importance=N_I, head=True)],
+                         ids=["weights", "no-fine-level", "labels-only", "labels-everywhere"])
+def test_sharded_render_world4_rank_without_rows(kw):
+    """H' = 5 over 4 ranks: rows per rank = 2, so rank 2 owns one row and rank 3 owns NONE.  The tile
+    layout comes from the arguments (never from what a rank happened to render), so the empty rank
+    joins every collective with the right shape; without importance samples no rank enters a
+    fine-level collective.  labels-only: features go to rank 0 only, 1-byte labels are broadcast."""
+    from gp_nerf_amd.render_image import shard_rows
+    H, W = 5, 6
+    rows, parts = shard_rows(H, 4)
+    assert rows == 2 and parts[3] == (5, 5) and parts[2] == (4, 5)
+    res = _run_world(4, H, W, kw)
+    one = _single(H, W, kw)
+    want_keys = {"rgb", "depth", "feats_out"} | ({"weights"} if kw.get("gather_weights") else set()) \
+        | ({"labels"} if kw.get("head") else set())
+    for r in range(4):
+        if kw["N_importance"] == 0:
+            assert res[r]["outputs_fine"] is None and one["outputs_fine"] is None
+        for lvl in ("outputs_coarse", "outputs_fine"):
+            if one[lvl] is None:
+                continue
+            keys = set(want_keys)
+            if kw.get("labels_only") and r != 0:
+                keys.discard("feats_out")  # features stay on rank 0 in labels-only mode
+            assert set(res[r][lvl]) == keys, (r, lvl, set(res[r][lvl]))
+            for k in keys:
+                assert np.array_equal(res[r][lvl][k], one[lvl][k].numpy()), (r, lvl, k)
+            if "labels" in keys:
+                assert res[r][lvl]["labels"].dtype == np.uint8 and res[r][lvl]["labels"].shape == (6, 6)
+    if kw.get("gather_weights"):
+        assert one["outputs_fine"]["weights"].shape == (H, W, N_S + N_I)
+        assert one["outputs_coarse"]["weights"].shape == (H, W, N_S)

@@ -20,6 +20,7 @@ EMB = 128
 SEM = 512
 NETWIDTH = 64
 VIEW_FOLD_FLOATS = 64 * 64 + 16 * 96 + 16
+STATIC_WS_BYTES = 64 << 20  # GPN_STATIC_WS_BYTES
 
 _f = C.POINTER(C.c_float)
 
@@ -113,6 +114,8 @@ _SIGS = {
     "gpn_gnt_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "gpn_gnt_forward": (C.c_int, [C.POINTER(GntWeights), _P, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int,
                                   C.c_int, C.POINTER(SemArgs), _P, _P, _P, _P, C.c_size_t, _P]),
+    "gpn_gnt_forward_static": (C.c_int, [C.POINTER(GntWeights), _P, C.c_int, _P, _P, _P, _P, _P, C.c_int,
+                                         C.c_int, C.c_int, C.POINTER(SemArgs), _P, _P, _P, _P]),
     "gpn_timing_begin": (C.c_int, [C.c_uint, C.c_int]),
     "gpn_timing_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
 }

@@ -13,6 +13,7 @@
 #include "common.h"
 #include "gnt_mfma.h"
 #include "proj_common.h"
+#include <mutex>
 #include <type_traits>
 
 #define C64 64
@@ -2394,4 +2395,61 @@ extern "C" int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat
     if ((rc = gpn_sem_aggregate(sem, stream))) return rc;
   }
   return gpn_heads(W, q, wts, z_vals, sem ? pre : nullptr, R, S, out, depth, sem_feat, stream);
+}
+
+// ------------------------------------------------------------------------------------ allocation-free forward
+// gpn_gnt_forward on a workspace that lives in the library's own device image instead of being
+// allocated by the caller (header: gpn_gnt_forward_static).  `scratch` is a host-side stand-in for the
+// array: its device address differs per GPU and is looked up once per device with
+// hipGetSymbolAddress; every use below goes through that pointer.
+static __device__ __align__(256) unsigned char scratch[GPN_STATIC_WS_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[kMaxDevices] = {};  // per device: that GPU's copy of `scratch`
+}  // namespace
+
+// device address of `scratch` on the current device (first call on a device: one symbol lookup)
+static int static_scratch(void** out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices)
+    return gpn_set_error(GPN_E_LAUNCH, "gpn_gnt_forward_static: no current HIP device (or index >= %d)",
+                         kMaxDevices);
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (g_scratch_ptr[dev] == nullptr) {
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || p == nullptr)
+      return gpn_set_error(GPN_E_LAUNCH, "gpn_gnt_forward_static: hipGetSymbolAddress(scratch) on device %d: %s",
+                           dev, hipGetErrorString(e));
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return GPN_OK;
+}
+
+extern "C" int gpn_gnt_forward_static(const gpn_gnt_weights_t* W, const float* rgb_feat, int rgb_feat_ld,
+                                      const float* ray_diff, const float* mask, const float* pts,
+                                      const float* ray_d, const float* z_vals, int R, int S, int V,
+                                      gpn_sem_args_t* sem, float* out, float* depth, float* sem_feat,
+                                      gpn_stream_t stream) {
+  if (R == 0) return GPN_OK;
+  GPN_REQUIRE(W, "gpn_gnt_forward_static: null pointer");
+  GPN_REQUIRE(R >= 0 && S >= 1 && S <= GPN_MAX_SAMPLES && V >= 1 && V <= GPN_MAX_VIEWS &&
+                  W->trans_depth >= 1 && W->trans_depth <= GPN_MAX_DEPTH,
+              "gpn_gnt_forward_static: unsupported shape R=%d S=%d V=%d depth=%d", R, S, V, W->trans_depth);
+  const size_t need = gnt_ws_layout(R, S, V, W->trans_depth).total;
+  GPN_REQUIRE(need <= (size_t)GPN_STATIC_WS_BYTES,
+              "gpn_gnt_forward_static: R=%d S=%d V=%d needs a %zu-byte workspace, the static one holds %zu "
+              "(GPN_STATIC_WS_BYTES): pass fewer rays per call, or use gpn_gnt_forward with a caller workspace",
+              R, S, V, need, (size_t)GPN_STATIC_WS_BYTES);
+  void* ws = nullptr;
+  int rc = static_scratch(&ws);
+  if (rc) return rc;
+  // every region of the workspace is written before it is read within one forward (the one counter
+  // that must start at zero, the visibility histogram, is cleared by gpn_vis_order on `stream`), so the
+  // previous call's contents are harmless; two calls in flight on one GPU would share it and race
+  return gpn_gnt_forward(W, rgb_feat, rgb_feat_ld, ray_diff, mask, pts, ray_d, z_vals, R, S, V, sem, out,
+                         depth, sem_feat, ws, need, stream);
 }

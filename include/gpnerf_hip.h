@@ -307,6 +307,24 @@ int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat, int rgb_f
                     int R, int S, int V, gpn_sem_args_t* sem, float* out, float* depth,
                     float* sem_feat, void* workspace, size_t workspace_bytes, gpn_stream_t stream);
 
+/* gpn_gnt_forward without a caller workspace and without any allocation.  It has NO counterpart in
+ * the reference: it exists for callers that cannot allocate device memory around the call -- code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  The workspace is a
+ * file-scope device array of GPN_STATIC_WS_BYTES inside the library's device image (every GPU the
+ * library runs on holds its own copy until the process ends); its address on the current device is
+ * looked up once per device, at this entry point's first call there (make that first call outside a
+ * graph capture).  Same arguments, results (bit for bit) and error behaviour as gpn_gnt_forward;
+ * additionally GPN_E_ARG when gpn_gnt_workspace_bytes(R, S, V, depth) > GPN_STATIC_WS_BYTES
+ * (64 MiB: e.g. 128 rays x 64 samples x 10 views at depth 8 -- a serving-loop tile, not a 4096-ray
+ * chunk).  Calls no hipMalloc / hipFree / allocating library routine.  All calls on one GPU share the
+ * one array: calls that overlap on a GPU (two streams, two threads) race -- order them. */
+#define GPN_STATIC_WS_BYTES (64u << 20)
+int gpn_gnt_forward_static(const gpn_gnt_weights_t* W, const float* rgb_feat, int rgb_feat_ld,
+                           const float* ray_diff, const float* mask, const float* pts,
+                           const float* ray_d, const float* z_vals, int R, int S, int V,
+                           gpn_sem_args_t* sem, float* out, float* depth, float* sem_feat,
+                           gpn_stream_t stream);
+
 /* ------------------------------------------------------------------ measurement hooks
  * No counterpart in the reference: bench.py uses these to time individual kernels with HIP events on
  * the stream they are launched on, inside the timed region.  gpn_timing_begin creates `max_records`

@@ -13,17 +13,27 @@ inputs resident in HBM, outputs left on the device.  With N>1 every rank renders
 chunk from its row shard of the image (weak scaling) and the rgb/depth/feats_out tiles of both
 levels are all-gathered over RCCL inside the timed region.
 
-Arithmetic: the default mode is "bf16x3" -- every fp32 product of the GNT linear layers is evaluated
-as three bf16 MFMAs on split operands with fp32 accumulation (include/gpnerf_hip.h); it meets the
-same 1e-4 parity bar as the exact-fp32 mode (tests/test_gpu_parity.py runs both).  The exact mode
-(fp32 MFMA, reference operation order) is timed too and reported under "fp32_exact".
+Arithmetic.  The HEADLINE (`value`, `dtype`, `roofline`, `path_mfma`) is the exact-fp32 mode: fp32 MFMA,
+fp32 accumulation, the reference's precision.  The faster "bf16x3" mode (every fp32 product as three
+bf16 MFMAs on split operands, fp32 accumulation, ~2^-16 per product; include/gpnerf_hip.h) meets the same
+1e-4 parity bar (tests/test_gpu_parity.py runs both) and is measured on the same workload under the key
+"bf16x3", with its own roofline blocks.  `--precision bf16x3` swaps the two.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_view_attn), which is
-HBM-bound: algorithmic bytes per launch / mean launch duration measured with HIP events inside the
-timed steps, against the 8 TB/s HBM peak; `traffic` = measured HBM bytes per launch (PMC passes,
-profiles/); `roofline.mfma` carries the same launch against the MFMA peak of the mode (SURVEY.md 8(d)
-reference-algorithm GEMM flops).  `cpu_baseline` is the CPU oracle (a port of the reference path) on a
-bounded ray sample.
+Prints ONE JSON line (rank 0):
+  roofline      the kernel with the largest share of the step in the headline mode.  fp32: an MFMA-bound
+                kernel -> bound "mfma", achieved = SURVEY.md 8(d) reference-algorithm flops per launch /
+                mean launch time (HIP events inside the timed steps, on the launch stream), peak = fp32
+                matrix peak.  bf16x3: k_view_attn, HBM-bound -> algorithmic bytes per launch / launch time
+                against 8 TB/s; `traffic` = HBM bytes per launch from the committed PMC passes under
+                profiles/ (NOT measured in this run: `traffic_source` says which file).
+  path_mfma     SURVEY.md 8(d) whole-path figure: F_ref (1.806 TFLOP per 4096-ray two-pass step, the
+                reference algorithm's GEMM-class flops whether or not the kernels execute them) / step
+                time, against the MFMA peak of the mode.
+  legs          the other 8(d) legs on the same scene: single_pass_64 (N_samples=64, N_importance=0: the
+                literal "4096 rays x 64 samples x 10 views"), dense_visibility (5 cm / no-yaw rig, near
+                plane 1 m: ~96 % of the (sample, view) pairs visible instead of ~41 %), projector_standalone
+                (Projector.compute with the 512-channel gather materialised, B_proj of SURVEY 8(d)).
+  cpu_baseline  the CPU oracle (a port of the reference path) on a bounded ray sample.
 """
 import argparse
 import json
@@ -45,6 +55,26 @@ HBM_PEAK_GBPS = 8000.0
 # what a bare copy kernel reaches on this GPU for k_view_attn's access shape (random 256-byte rows,
 # read + written; tools/micro/reqbench.hip, profiles/r01_reqbench.txt); sequential read-only: 6250
 RANDOM_ROW_RW_CEILING_GBPS = 4700.0
+TRAFFIC_FILE = "profiles/r02_pmc_traffic.json"
+
+RIGS = {
+    # 15 cm / 5 cm offsets, 2 degrees of yaw per view, depth 0.1-10 m (mask mean ~0.41)
+    "sparse": dict(rig=dict(), depth=(0.1, 10.0)),
+    # the survey's tight rig: 5 cm spacing, no rotation; near plane at 1 m (mask mean ~0.96)
+    "dense": dict(rig=dict(dx=0.05, dy=0.0, yaw_deg=0.0), depth=(1.0, 6.0)),
+}
+
+
+# ---------------------------------------------------------------------------------------- flop / byte models
+def f_ref_per_sample(V, S):
+    """reference-algorithm GEMM-class flops (MAC = 2) of one sample evaluation in a
+    pass of S samples: rgbfeat + 8 x (view layer + ray layer) + 4 x q positional MLP."""
+    return V * 12672 + 8 * (V * 20544 + 81920 + 98304 + 1280 * S) + 4 * 32512
+
+
+def f_ref_per_ray(V, samples):
+    """One render_rays call = one pass per entry of `samples`; + the 512x512 adaptor per pass."""
+    return sum(S * f_ref_per_sample(V, S) + 524288 for S in samples)
 
 
 def view_attn_flops_per_point(V):
@@ -55,7 +85,9 @@ def view_attn_flops_per_point(V):
     return V * (2 * 8192 + 1088 + 2048) + 2 * 8192
 
 
-# MFMA flops the kernel executes (MAC = 2; every bf16x3 product counts its three MFMAs).
+FF_FLOPS_PER_POINT = 2 * 2 * 64 * 256  # fc1 + fc2 of one FeedForward (the FF share of 81,920 / 98,304)
+
+# MFMA flops k_view_attn executes (MAC = 2; every bf16x3 product counts its three MFMAs).
 # bf16x3 (folded weights): per computed pair (Wv Wk) 8192 + pos_fc[2] 1024 + (A0 Wk | A0 P2) 1152 +
 # attn_fc[2] 1024 = 11392, x3; + fp32 pos_fc[0] 64.  Per point q_fc + out_fc + A0 q = 17408, x3.
 # fp32: the reference order, k 8192 + v 8192 + pos 64 + 1024 + attn 1024 + 1024 per pair, 16384 per point.
@@ -63,40 +95,26 @@ VIEW_EXEC_FLOPS_PER_PAIR = {"bf16x3": 3 * 11392 + 64, "fp32": 19520}
 VIEW_EXEC_FLOPS_PER_POINT = {"bf16x3": 3 * 17408, "fp32": 16384}
 
 
+def mfma_peak(precision):
+    if precision == "bf16x3":
+        return BF16_MATRIX_PEAK_TFLOPS / 3.0, "dense bf16 MFMA peak / 3 (three bf16 MFMAs per fp32 product)"
+    return FP32_MATRIX_PEAK_TFLOPS, "fp32 MFMA peak"
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 as the
-    gfx950 correction + WRITE_SIZE, separate runs of this same command): profiles/r01_pmc_traffic.json.
-    None if the file is missing."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f)[kernel]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+    gfx950 correction + WRITE_SIZE, separate runs of this same command).  None if the file is missing."""
+    for name in (TRAFFIC_FILE, "profiles/r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, name)) as f:
+                return json.load(f)[kernel]["hbm_bytes_per_launch"], name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
-def visibility_stats(scene, rb, ret, projector):
-    """Fractions of (sample, view) pairs the view transformer has to compute / that are visible, over
-    the two passes of one step (coarse samples + the fine samples derived from the coarse weights)."""
-    from gp_nerf_amd import render_ray as rr
-    sv = projector.prepare(rb["camera"], rb["src_rgbs"], rb["src_cameras"], scene.featmaps, scene.deep)
-    pts_c, z_c = rr.sample_along_camera_ray(rb["ray_o"], rb["ray_d"], rb["depth_range"], N_SAMPLES,
-                                            inv_uniform=True, det=True)
-    pts_f, _ = rr.sample_fine_pts(True, N_IMPORTANCE, True, N_SAMPLES, rb,
-                                  ret["outputs_coarse"]["weights"], z_c)
-    vis_pairs = comp_pairs = pts = 0
-    for p in (pts_c, pts_f):
-        _, _, mask = projector.compute_fused(p, sv)
-        m = mask.reshape(-1, VIEWS) != 0
-        nvis = m.sum(-1)
-        vis_pairs += int(nvis.sum())
-        comp_pairs += int(torch.where(nvis == 0, torch.full_like(nvis, VIEWS), nvis).sum())
-        pts += m.shape[0]
-    return {"visible_pair_fraction": vis_pairs / (pts * VIEWS),
-            "computed_pair_fraction": comp_pairs / (pts * VIEWS)}
-
-
-def build(dev, seed=1234):
+# ---------------------------------------------------------------------------------------- scene
+def build(dev, seed=1234, rig="sparse"):
     from gp_nerf_amd import synth
     from gp_nerf_amd.projection import Projector
     from gp_nerf_amd.transformer_network import GNT
@@ -104,12 +122,13 @@ def build(dev, seed=1234):
 
     H, W = 480, 640
     K = synth.REPLICA_K
+    cfg = RIGS[rig]
     g = torch.Generator(device=dev).manual_seed(seed)
     scene = types.SimpleNamespace()
-    scene.H, scene.W = H, W
+    scene.H, scene.W, scene.rig = H, W, rig
     scene.camera = torch.from_numpy(synth.make_camera(H, W, K, np.eye(4)))[None].to(dev)
-    scene.src_cameras = torch.from_numpy(synth.source_rig(VIEWS, H, W, K))[None].to(dev)
-    scene.depth_range = torch.tensor([[0.1, 10.0]], device=dev)
+    scene.src_cameras = torch.from_numpy(synth.source_rig(VIEWS, H, W, K, **cfg["rig"]))[None].to(dev)
+    scene.depth_range = torch.tensor([list(cfg["depth"])], device=dev)
     scene.src_rgbs = torch.rand((1, VIEWS, H, W, 3), device=dev, generator=g)
     scene.featmaps = torch.randn((VIEWS, 32, H // 4, W // 4), device=dev, generator=g)
     scene.deep = torch.randn((VIEWS, 512, H // 2, W // 2), device=dev, generator=g)
@@ -120,6 +139,18 @@ def build(dev, seed=1234):
     net.load_state_dict(synth.gnt_state_dict())
     net = net.to(dev).eval()
     return scene, net, Projector(dev)
+
+
+def rerig(scene, rig, dev):
+    """The same maps / weights seen through another source rig (cameras and depth range only)."""
+    from gp_nerf_amd import synth
+    cfg = RIGS[rig]
+    other = types.SimpleNamespace(**vars(scene))
+    other.rig = rig
+    other.src_cameras = torch.from_numpy(synth.source_rig(VIEWS, scene.H, scene.W, synth.REPLICA_K,
+                                                          **cfg["rig"]))[None].to(dev)
+    other.depth_range = torch.tensor([list(cfg["depth"])], device=dev)
+    return other
 
 
 def ray_chunk(scene, rank, world, dev):
@@ -133,6 +164,28 @@ def ray_chunk(scene, rank, world, dev):
     return {"ray_o": scene.rays_o[sl].to(dev), "ray_d": scene.rays_d[sl].to(dev),
             "depth_range": scene.depth_range, "camera": scene.camera,
             "src_rgbs": scene.src_rgbs, "src_cameras": scene.src_cameras}
+
+
+def visibility_stats(scene, rb, projector, n_samples, n_importance, coarse_weights=None):
+    """Fractions of (sample, view) pairs the view transformer has to compute / that are visible, over
+    the passes of one step (coarse samples + the fine samples derived from the coarse weights)."""
+    from gp_nerf_amd import render_ray as rr
+    sv = projector.prepare(rb["camera"], rb["src_rgbs"], rb["src_cameras"], scene.featmaps, scene.deep)
+    pts_c, z_c = rr.sample_along_camera_ray(rb["ray_o"], rb["ray_d"], rb["depth_range"], n_samples,
+                                            inv_uniform=True, det=True)
+    passes = [pts_c]
+    if n_importance > 0:
+        passes.append(rr.sample_fine_pts(True, n_importance, True, n_samples, rb, coarse_weights, z_c)[0])
+    vis_pairs = comp_pairs = pts = 0
+    for p in passes:
+        _, _, mask = projector.compute_fused(p, sv)
+        m = mask.reshape(-1, VIEWS) != 0
+        nvis = m.sum(-1)
+        vis_pairs += int(nvis.sum())
+        comp_pairs += int(torch.where(nvis == 0, torch.full_like(nvis, VIEWS), nvis).sum())
+        pts += m.shape[0]
+    return {"visible_pair_fraction": vis_pairs / (pts * VIEWS),
+            "computed_pair_fraction": comp_pairs / (pts * VIEWS)}
 
 
 def cpu_baseline(scene, rb, n_rays):
@@ -162,11 +215,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-rays", type=int, default=1536, help="rays of the CPU baseline sample (0: skip)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-stage time table to stderr")
-    ap.add_argument("--precision", default="bf16x3", choices=("fp32", "bf16x3"),
-                    help="arithmetic of the GNT linear layers (see include/gpnerf_hip.h)")
+    ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16x3"),
+                    help="arithmetic of the headline numbers (the other mode is reported under its own key)")
     ap.add_argument("--only-timed", action="store_true",
-                    help="skip the other arithmetic mode, the full-image run and the CPU baseline "
+                    help="skip the other arithmetic mode, the extra legs, the full-image run and the CPU baseline "
                          "(tools/profile_round.sh: the profiled kernels are then the timed workload only)")
+    ap.add_argument("--leg", default=None, choices=("single_pass_64", "dense_visibility", "projector_standalone"),
+                    help="run ONLY this leg as the timed workload (profiling aid; prints the leg's block)")
     a = ap.parse_args()
     if a.only_timed:
         a.cpu_rays = 0
@@ -199,27 +254,28 @@ def main():
     from gp_nerf_amd.render_ray import render_rays
     _lib.lib()
     scene, net, projector = build(dev)
-    net.precision = a.precision
     model = types.SimpleNamespace(net_coarse=net, net_fine=None)
     rb = ray_chunk(scene, rank, world, dev)
     tile_w = 2 * (3 + 1 + 512)
     gathered = torch.empty((world * CHUNK, tile_w), device=dev) if world > 1 else None
 
-    def step(collective=True):
-        ret = render_rays(rb, model, scene.featmaps, scene.deep, projector, N_samples=N_SAMPLES,
-                          inv_uniform=True, N_importance=N_IMPORTANCE, det=True, ret_alpha=True,
-                          single_net=True)
-        if world > 1 and collective:  # rgb / depth / semantic tiles of both levels, one collective
-            c, f = ret["outputs_coarse"], ret["outputs_fine"]
-            tile = torch.cat([c["rgb"], c["depth"][:, None], c["feats_out"],
-                              f["rgb"], f["depth"][:, None], f["feats_out"]], dim=1)
-            if rehearse:  # gloo stages device tensors through the host unreliably: gather host copies
-                host = torch.empty((world * CHUNK, tile_w))
-                dist.all_gather_into_tensor(host, tile.cpu())
-                gathered.copy_(host)
-            else:
-                dist.all_gather_into_tensor(gathered, tile)
-        return ret
+    def make_step(sc, batch, n_samples, n_importance):
+        def step(collective=True):
+            ret = render_rays(batch, model, sc.featmaps, sc.deep, projector, N_samples=n_samples,
+                              inv_uniform=True, N_importance=n_importance, det=True, ret_alpha=True,
+                              single_net=True)
+            if world > 1 and collective:  # rgb / depth / semantic tiles of both levels, one collective
+                c, f = ret["outputs_coarse"], ret["outputs_fine"] or ret["outputs_coarse"]
+                tile = torch.cat([c["rgb"], c["depth"][:, None], c["feats_out"],
+                                  f["rgb"], f["depth"][:, None], f["feats_out"]], dim=1)
+                if rehearse:  # gloo stages device tensors through the host unreliably: gather host copies
+                    host = torch.empty((world * CHUNK, tile_w))
+                    dist.all_gather_into_tensor(host, tile.cpu())
+                    gathered.copy_(host)
+                else:
+                    dist.all_gather_into_tensor(gathered, tile)
+            return ret
+        return step
 
     def fence():
         torch.cuda.synchronize()
@@ -227,14 +283,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(precision, steps, warmup):
-        """W warm-up steps, then K steps between fences; max over ranks; k_view_attn event-timed."""
+    TIMED_STAGES = ("view_attn", "ff")  # the two candidates for the dominant kernel
+
+    def timed(step, precision, steps, warmup):
+        """W warm-up steps, then K steps between fences; max over ranks; the candidate dominant kernels
+        are event-timed on the launch stream inside the timed steps."""
         net.precision = precision
         for _ in range(warmup):
             r = step()
         fence()
         t0 = time.perf_counter()
-        with _lib.stage_timing(stages=("view_attn",), max_records=32 * steps + 64) as tm_:
+        with _lib.stage_timing(stages=TIMED_STAGES, max_records=96 * steps + 64) as tm_:
             for _ in range(steps):
                 r = step()
             fence()
@@ -245,62 +304,122 @@ def main():
             dt = float(t.item())
         return r, dt, tm_
 
-    ret, elapsed, tm = timed(a.precision, a.steps, a.warmup)
-
-    # dominant kernel: k_view_attn, 8 launches on N=4096*48 points + 8 on N=4096*64 per step.
-    # It is HBM-bound (51 % of the 8 TB/s peak in measured traffic, 86 % of the
-    # ceiling a bare copy kernel reaches for the same access shape -- random 256-byte rows read and
-    # written; its time follows its bytes, not its instruction count), so the roofline is the HBM one:
-    # achieved = ALGORITHMIC bytes per launch / mean launch time.
-    launches = tm.launches["view_attn"]
-    mean_ms = tm.ms["view_attn"] / max(1, launches)
-    pts_per_launch = CHUNK * (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) / 2.0
-    vstat = visibility_stats(scene, rb, ret, projector)
-    live = vstat["computed_pair_fraction"]
-    # per computed (point, view) pair: feature row 256 B + ray_diff 16 B; per visible pair: the 8
-    # hidden values of attn_fc 32 B; per point: q in 256 + q out 256 + softmax stats 256 + order /
-    # visibility words 8
-    alg_bytes = (VIEWS * live * (256 + 16) + VIEWS * vstat["visible_pair_fraction"] * 32 +
-                 256 + 256 + 256 + 8) * pts_per_launch
-    achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
-    traffic = pmc_traffic("k_view_attn")
-    roofline = {"bound": "hbm", "kernel": "k_view_attn", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "launches": launches, "mean_launch_ms": mean_ms,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "traffic_GBps": (traffic / (mean_ms * 1e-3) / 1e9) if traffic else None,
-                "access_shape_ceiling_GBps": RANDOM_ROW_RW_CEILING_GBPS,
-                "visibility": vstat}
-    # the same launch against the MFMA roofline (reference-algorithm GEMM flops, whether or not the
-    # kernel executes them; executed flops alongside)
-    flops_per_launch = view_attn_flops_per_point(VIEWS) * pts_per_launch
-    if a.precision == "bf16x3":
-        peak, peak_note = BF16_MATRIX_PEAK_TFLOPS / 3.0, "dense bf16 MFMA peak / 3 (three bf16 MFMAs per product)"
-    else:
-        peak, peak_note = FP32_MATRIX_PEAK_TFLOPS, "fp32 MFMA peak"
-    ex_flops = (VIEWS * live * VIEW_EXEC_FLOPS_PER_PAIR[a.precision] +
-                VIEW_EXEC_FLOPS_PER_POINT[a.precision]) * pts_per_launch
-    roofline["mfma"] = {"achieved_TFLOPs": flops_per_launch / (mean_ms * 1e-3) / 1e12, "peak_TFLOPs": peak,
-                        "frac": flops_per_launch / (mean_ms * 1e-3) / 1e12 / peak, "peak_note": peak_note,
-                        "flops_per_launch": flops_per_launch,
-                        "executed_mfma_TFLOPs": ex_flops / (mean_ms * 1e-3) / 1e12}
-
-    other = None
-    if not a.only_timed:  # the other arithmetic mode on the same workload (shorter run; every rank takes part)
-        omode = "fp32" if a.precision == "bf16x3" else "bf16x3"
-        _, dt_o, _ = timed(omode, max(3, a.steps // 2), 2)
-        other = {"precision": omode, "value": world * CHUNK * max(3, a.steps // 2) / dt_o,
-                 "ms_per_step": 1e3 * dt_o / max(3, a.steps // 2)}
-        net.precision = a.precision
-
-    stages = None
-    if a.breakdown or rank == 0:
+    def stage_breakdown(step, precision):
+        net.precision = precision
         with _lib.stage_timing() as tb:  # one extra, untimed step with every stage instrumented
             step(collective=False)  # rank-local: not every rank runs this block
             torch.cuda.synchronize()
-        stages = {k: round(v, 4) for k, v in tb.ms.items() if tb.launches[k]}
-        if a.breakdown and rank == 0:
-            print("per-stage ms (one step):", json.dumps(stages), file=sys.stderr)
+        return {k: round(v, 4) for k, v in tb.ms.items() if tb.launches[k]}
+
+    def rooflines(precision, tm, dt, steps, samples, vstat):
+        """roofline of the dominant kernel of this mode + the whole-path MFMA figure."""
+        pts_per_launch = CHUNK * sum(samples) / float(len(samples))
+        live = vstat["computed_pair_fraction"]
+        peak, peak_note = mfma_peak(precision)
+        blocks = {}
+        # ---- k_view_attn against the HBM roofline (its bound in bf16x3 mode)
+        n_va = max(1, tm.launches["view_attn"])
+        va_ms = tm.ms["view_attn"] / n_va
+        # per computed (point, view) pair: feature row 256 B + ray_diff 16 B; per visible pair: the 8 hidden
+        # values of attn_fc 32 B; per point: q in 256 + q out 256 + order / visibility words 8
+        # (+ 256 of softmax statistics while that side output exists: see VIEW_STATS_BYTES)
+        alg_bytes = (VIEWS * live * (256 + 16) + VIEWS * vstat["visible_pair_fraction"] * 32 +
+                     256 + 256 + VIEW_STATS_BYTES + 8) * pts_per_launch
+        traffic, tsrc = pmc_traffic("k_view_attn" if precision == "bf16x3" else "k_view_attn_fp32")
+        va_flops = view_attn_flops_per_point(VIEWS) * pts_per_launch
+        ex_flops = (VIEWS * live * VIEW_EXEC_FLOPS_PER_PAIR[precision] +
+                    VIEW_EXEC_FLOPS_PER_POINT[precision]) * pts_per_launch
+        blocks["k_view_attn"] = {
+            "hbm": {"bound": "hbm", "kernel": "k_view_attn", "achieved": alg_bytes / (va_ms * 1e-3) / 1e9,
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_bytes / (va_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    "traffic": traffic, "traffic_source": ("%s (rocprofv3 PMC passes of this command; NOT measured "
+                                                           "in this run)" % tsrc) if tsrc else None,
+                    "launches": tm.launches["view_attn"], "mean_launch_ms": va_ms,
+                    "algorithmic_bytes_per_launch": alg_bytes,
+                    "traffic_GBps": (traffic / (va_ms * 1e-3) / 1e9) if traffic else None,
+                    "access_shape_ceiling_GBps": RANDOM_ROW_RW_CEILING_GBPS},
+            "mfma": {"bound": "mfma", "kernel": "k_view_attn", "achieved": va_flops / (va_ms * 1e-3) / 1e12,
+                     "peak": peak, "unit": "TFLOP/s", "frac": va_flops / (va_ms * 1e-3) / 1e12 / peak,
+                     "traffic": traffic, "peak_note": peak_note, "launches": tm.launches["view_attn"],
+                     "mean_launch_ms": va_ms, "algorithmic_flops_per_launch": va_flops,
+                     "executed_mfma_TFLOPs": ex_flops / (va_ms * 1e-3) / 1e12},
+            "step_share": tm.ms["view_attn"] / steps / (1e3 * dt / steps)}
+        # ---- k_ff against the MFMA roofline
+        n_ff = max(1, tm.launches["ff"])
+        ff_ms = tm.ms["ff"] / n_ff
+        ff_flops = FF_FLOPS_PER_POINT * pts_per_launch
+        ftraffic, fsrc = pmc_traffic("k_ff" if precision == "bf16x3" else "k_ff_fp32")
+        blocks["k_ff"] = {
+            "mfma": {"bound": "mfma", "kernel": "k_ff", "achieved": ff_flops / (ff_ms * 1e-3) / 1e12, "peak": peak,
+                     "unit": "TFLOP/s", "frac": ff_flops / (ff_ms * 1e-3) / 1e12 / peak, "traffic": ftraffic,
+                     "traffic_source": ("%s (rocprofv3 PMC passes of this command; NOT measured in this run)" % fsrc)
+                     if fsrc else None,
+                     "peak_note": peak_note, "launches": tm.launches["ff"], "mean_launch_ms": ff_ms,
+                     "algorithmic_flops_per_launch": ff_flops},
+            "step_share": tm.ms["ff"] / steps / (1e3 * dt / steps)}
+        # dominant = larger share of the step; each kernel priced against the roofline that bounds it in
+        # this mode (bf16x3: k_view_attn is HBM-bound, DESIGN.md section 6; fp32: both are MFMA-bound)
+        dom = "k_view_attn" if blocks["k_view_attn"]["step_share"] >= blocks["k_ff"]["step_share"] else "k_ff"
+        if dom == "k_view_attn":
+            main_ = dict(blocks[dom]["hbm" if precision == "bf16x3" else "mfma"])
+            if precision == "bf16x3":
+                main_["mfma"] = blocks[dom]["mfma"]
+            else:
+                main_["hbm"] = blocks[dom]["hbm"]
+        else:
+            main_ = dict(blocks[dom]["mfma"])
+        main_["step_share"] = blocks[dom]["step_share"]
+        main_["visibility"] = vstat
+        other = "k_ff" if dom == "k_view_attn" else "k_view_attn"
+        main_["second_kernel"] = dict(blocks[other]["mfma"] if (other == "k_ff" or precision == "fp32")
+                                      else blocks[other]["hbm"], step_share=blocks[other]["step_share"])
+        f_ref = f_ref_per_ray(VIEWS, samples) * CHUNK * world
+        t_step = dt / steps
+        path = {"F_ref_TFLOP_per_step": f_ref / 1e12, "achieved_TFLOPs": f_ref / t_step / 1e12,
+                "peak_TFLOPs": peak * world, "frac": f_ref / t_step / 1e12 / (peak * world), "peak_note": peak_note,
+                "note": "SURVEY.md 8(d): reference-algorithm GEMM-class flops per step / step time; the kernels "
+                        "execute fewer (views with zero attention weight are skipped exactly: "
+                        "computed_pair_fraction)"}
+        return main_, path
+
+    def measure(step, precision, steps, warmup, samples, sc, batch, n_s, n_i):
+        ret, dt, tm = timed(step, precision, steps, warmup)
+        cw = ret["outputs_coarse"]["weights"] if n_i > 0 else None
+        vstat = visibility_stats(sc, batch, projector, n_s, n_i, cw)
+        roof, path = rooflines(precision, tm, dt, steps, samples, vstat)
+        return ret, {"precision": precision, "value": world * CHUNK * steps / dt, "unit": "rays/s",
+                     "ms_per_step": 1e3 * dt / steps, "roofline": roof, "path_mfma": path}
+
+    two_pass = make_step(scene, rb, N_SAMPLES, N_IMPORTANCE)
+    samples2 = [N_SAMPLES, N_SAMPLES + N_IMPORTANCE]
+
+    # ------------------------------------------------------------------ profiling aid: one leg only
+    if a.leg is not None:
+        print(json.dumps(run_leg(a.leg, a, dev, scene, rb, net, model, projector, make_step, measure,
+                                 stage_breakdown, world, rank)))
+        return
+
+    ret, head = measure(two_pass, a.precision, a.steps, a.warmup, samples2, scene, rb, N_SAMPLES, N_IMPORTANCE)
+    stages = stage_breakdown(two_pass, a.precision) if (a.breakdown or rank == 0) else None
+    if a.breakdown and rank == 0:
+        print("per-stage ms (one step, %s):" % a.precision, json.dumps(stages), file=sys.stderr)
+
+    other = None
+    omode = "bf16x3" if a.precision == "fp32" else "fp32"
+    if not a.only_timed:  # the other arithmetic mode on the same workload (every rank takes part)
+        ret_o, other = measure(two_pass, omode, a.steps, 2, samples2, scene, rb, N_SAMPLES, N_IMPORTANCE)
+        if rank == 0:
+            other["stage_ms_one_step"] = stage_breakdown(two_pass, omode)
+        net.precision = a.precision
+    else:
+        ret_o = None
+
+    legs = None
+    if rank == 0 and world == 1 and not a.only_timed:
+        legs = {name: run_leg(name, a, dev, scene, rb, net, model, projector, make_step, measure,
+                              stage_breakdown, world, rank)
+                for name in ("single_pass_64", "dense_visibility", "projector_standalone")}
+        net.precision = a.precision
 
     # secondary metric (SURVEY.md 8(d)): seconds per full image through render_single_image, results
     # on the host (BASELINE configs[1]: Replica 640x480, render_stride 2 as in gpnerf_replica.txt)
@@ -313,82 +432,170 @@ def main():
         rbi = dict(rb)
         rbi["ray_o"], rbi["ray_d"] = scene.rays_o[idx].to(dev), scene.rays_d[idx].to(dev)
         sampler = types.SimpleNamespace(H=scene.H, W=scene.W)
-        best = None
-        for _ in range(3):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            render_single_image(sampler, rbi, model, projector, CHUNK, N_SAMPLES, inv_uniform=True,
-                                N_importance=N_IMPORTANCE, det=True, render_stride=stride,
-                                featmaps=scene.featmaps, deep_semantics=scene.deep, ret_alpha=True,
-                                single_net=True, feats_out_3d=False)
-            torch.cuda.synchronize()
-            dt_i = time.perf_counter() - t0
-            best = dt_i if best is None else min(best, dt_i)
         full_image = {"workload": "render_single_image, replica 640x480 render_stride 2 (%d rays), chunk %d, "
                                   "rgb/depth/weights/feats_out of both levels copied to the host; "
-                                  "feats_out_3d not materialised" % (idx.numel(), CHUNK),
-                      "seconds_per_image": best, "rays_per_sec": idx.numel() / best}
+                                  "feats_out_3d not materialised" % (idx.numel(), CHUNK)}
+        for mode in (a.precision, omode):
+            net.precision = mode
+            best = None
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                render_single_image(sampler, rbi, model, projector, CHUNK, N_SAMPLES, inv_uniform=True,
+                                    N_importance=N_IMPORTANCE, det=True, render_stride=stride,
+                                    featmaps=scene.featmaps, deep_semantics=scene.deep, ret_alpha=True,
+                                    single_net=True, feats_out_3d=False)
+                torch.cuda.synchronize()
+                dt_i = time.perf_counter() - t0
+                best = dt_i if best is None else min(best, dt_i)
+            full_image[mode] = {"seconds_per_image": best, "rays_per_sec": idx.numel() / best}
+        net.precision = a.precision
 
     cpu = None
     if rank == 0 and world == 1 and a.cpu_rays > 0:
         want, cpu = cpu_baseline(scene, rb, a.cpu_rays)
-        # The 16 importance samples are an inverse-CDF lookup of the coarse weights, and visibility is
-        # a hard in-frustum test: a 1e-7 change of the coarse weights can move a sample across a CDF
-        # bin edge or across the border of a source image (reference behaviour, any two platforms
-        # differ this way).  Rays whose fine depths or visibility masks differ between the GPU run
-        # and the CPU run are counted and left out of the fine-level comparison.
-        import oracle
-        nr = a.cpu_rays
-        rbc = {k: v.cpu() for k, v in rb.items()}
-        rbc["ray_o"], rbc["ray_d"] = rbc["ray_o"][:nr], rbc["ray_d"][:nr]
-        _, zc = oracle.sampling.sample_along_camera_ray(rbc["ray_o"], rbc["ray_d"], rbc["depth_range"],
-                                                        N_SAMPLES, inv_uniform=True, det=True)
-        zf = [oracle.sampling.sample_fine_pts(True, N_IMPORTANCE, True, N_SAMPLES, rbc, w.clone(), zc)[1]
-              for w in (ret["outputs_coarse"]["weights"][:nr].cpu(), want["outputs_coarse"]["weights"])]
-        same = ((zf[0] - zf[1]).abs().amax(-1) <= 1e-4 * zf[1].abs().amax(-1))
-        # visibility of the fine samples: the GPU pipeline's own points vs the oracle's
-        from gp_nerf_amd import render_ray as rr
-        sv = projector.prepare(rb["camera"], rb["src_rgbs"], rb["src_cameras"], scene.featmaps, scene.deep)
-        rbg = dict(rb)
-        rbg["ray_o"], rbg["ray_d"] = rb["ray_o"][:nr], rb["ray_d"][:nr]
-        pg, _ = rr.sample_fine_pts(True, N_IMPORTANCE, True, N_SAMPLES, rbg,
-                                   ret["outputs_coarse"]["weights"][:nr], zc.to(dev))
-        m_gpu = (projector.compute_fused(pg, sv)[2].reshape(nr, -1, VIEWS) != 0).cpu()
-        pc, _ = oracle.sampling.sample_fine_pts(True, N_IMPORTANCE, True, N_SAMPLES, rbc,
-                                                want["outputs_coarse"]["weights"].clone(), zc)
-        pix, front = oracle.projector.compute_projections(pc, rbc["src_cameras"][0])
-        m_cpu = (oracle.projector.inbound(pix, float(scene.H), float(scene.W)) & front).permute(1, 2, 0)
-        same &= (m_gpu == m_cpu).reshape(nr, -1).all(dim=-1)
-        worst = 0.0
-        for lvl in ("outputs_coarse", "outputs_fine"):
-            for k in ("rgb", "depth", "weights", "feats_out"):
-                x, y = ret[lvl][k][:nr].cpu(), want[lvl][k]
-                if lvl == "outputs_fine":
-                    x, y = x[same], y[same]
-                worst = max(worst, float((x - y).abs().max() / max(1.0, float(y.abs().max()))))
-        cpu["max_rel_err_gpu_vs_cpu"] = worst
-        cpu["fine_rays_resampled"] = int((~same).sum())
+        for mode, r in ((a.precision, ret), (omode, ret_o)):
+            if r is not None:
+                err, resampled = compare_with_cpu(scene, rb, projector, r, want, a.cpu_rays, dev)
+                cpu["max_rel_err_gpu_vs_cpu_" + mode] = err
+                cpu["fine_rays_resampled_" + mode] = resampled
 
     if rank == 0:
-        rays = world * CHUNK * a.steps
         line = {
-            "metric": "rays_per_sec", "value": rays / elapsed, "unit": "rays/s", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "metric": "rays_per_sec", "value": head["value"], "unit": "rays/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if a.precision == "fp32" else "f32 (bf16x3 split-operand MFMA, fp32 accumulate)",
+            "headline_precision": a.precision,
             "data": "synthetic",
             "config": {"workload": "replica_640x480_10views render_rays chunk=%d rays/GPU, "
                                    "coarse 48 + importance 16 (48- and 64-sample passes)" % CHUNK,
                        "precision": a.precision,
-                       "rays_per_step_per_gpu": CHUNK, "samples": [N_SAMPLES, N_SAMPLES + N_IMPORTANCE],
+                       "rays_per_step_per_gpu": CHUNK, "samples": samples2,
                        "views": VIEWS, "parallelism": "ray-sharded x%d" % world},
-            "roofline": roofline, "cpu_baseline": cpu,
-            "fp32_exact" if a.precision == "bf16x3" else "bf16x3": other,
-            "stage_ms_one_step": stages, "full_image": full_image,
+            "roofline": head["roofline"], "path_mfma": head["path_mfma"], "cpu_baseline": cpu,
+            omode: other, "stage_ms_one_step": stages, "legs": legs, "full_image": full_image,
         }
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+# softmax statistics written per point by gpn_view_attn for the semantic pass (0 once that side
+# channel is gone: gpn_sem_aggregate then rebuilds the log-sum-exp from the hidden values)
+VIEW_STATS_BYTES = 256
+
+
+def run_leg(name, a, dev, scene, rb, net, model, projector, make_step, measure, stage_breakdown, world, rank):
+    """One of the SURVEY.md 8(d) legs beside the headline workload; both arithmetic modes where the
+    GNT is involved.  Returns the leg's JSON block."""
+    from gp_nerf_amd import _lib
+    steps = max(5, a.steps // 2)
+    if name == "single_pass_64":
+        step = make_step(scene, rb, 64, 0)
+        out = {"workload": "render_rays, N_samples=64, N_importance=0 (one 64-sample pass: 4096 rays x 64 samples "
+                           "x 10 views), same scene and chunk"}
+        for mode in ("fp32", "bf16x3"):
+            _, m = measure(step, mode, steps, 2, [64], scene, rb, 64, 0)
+            m["stage_ms_one_step"] = stage_breakdown(step, mode)
+            out[mode] = m
+        return out
+    if name == "dense_visibility":
+        dense = rerig(scene, "dense", dev)
+        rbd = dict(rb)
+        rbd["depth_range"], rbd["src_cameras"] = dense.depth_range, dense.src_cameras
+        step = make_step(dense, rbd, N_SAMPLES, N_IMPORTANCE)
+        out = {"workload": "two-pass render_rays as the headline, source rig 5 cm apart / no rotation, depth "
+                           "1-6 m: nearly every (sample, view) pair is visible (roofline.visibility)"}
+        for mode in ("fp32", "bf16x3"):
+            _, m = measure(step, mode, steps, 2, [N_SAMPLES, N_SAMPLES + N_IMPORTANCE], dense, rbd,
+                           N_SAMPLES, N_IMPORTANCE)
+            m["stage_ms_one_step"] = stage_breakdown(step, mode)
+            out[mode] = m
+        return out
+    if name == "projector_standalone":
+        # north_star subsystem 1: Projector.compute with the 512-channel deep-semantic gather
+        # materialised (reference projection.py:84-139) at the north-star shape
+        from gp_nerf_amd import render_ray as rr
+        S = 64
+        pts, _ = rr.sample_along_camera_ray(rb["ray_o"], rb["ray_d"], rb["depth_range"], S, inv_uniform=True,
+                                            det=True)
+        R = pts.shape[0]
+        H, W = scene.H, scene.W
+
+        def call():
+            return projector.compute(pts, rb["camera"], rb["src_rgbs"], rb["src_cameras"], scene.featmaps,
+                                     scene.deep)
+        for _ in range(2):
+            out4 = call()
+        torch.cuda.synchronize()
+        mask_mean = float(out4[3].mean())
+        del out4
+        t0 = time.perf_counter()
+        with _lib.stage_timing(stages=("project", "project_deep"), max_records=4 * steps + 8) as tm:
+            for _ in range(steps):
+                o = call()
+                del o
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        # SURVEY.md 8(d) B_proj: outputs written once + every map byte read once + the points
+        b_out = R * S * VIEWS * (35 + 512 + 4 + 1) * 4
+        b_maps = VIEWS * 4 * (3 * H * W + 32 * (H // 4) * (W // 4) + 512 * (H // 2) * (W // 2))
+        b_proj = b_out + b_maps + R * S * 12
+        k_ms = {k: tm.ms[k] / max(1, tm.launches[k]) for k in ("project", "project_deep")}
+        t_k = (k_ms["project"] + k_ms["project_deep"]) * 1e-3
+        deep_bytes = R * S * VIEWS * 512 * 4
+        traffic, tsrc = pmc_traffic("k_project_deep")
+        return {"workload": "Projector.compute, R=%d S=%d V=%d, maps of a 640x480 image, deep-semantic gather "
+                            "materialised ([R,S,V,512] = %.2f GB written)" % (R, S, VIEWS, deep_bytes / 1e9),
+                "mask_mean": mask_mean, "ms_per_call": 1e3 * dt / steps, "rays_per_sec": R * steps / dt,
+                "kernel_ms": {"k_project_feat": k_ms["project"], "k_project_deep": k_ms["project_deep"]},
+                "roofline": {"bound": "hbm", "kernel": "k_project_feat + k_project_deep", "achieved": b_proj / t_k / 1e9,
+                             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": b_proj / t_k / 1e9 / HBM_PEAK_GBPS,
+                             "algorithmic_bytes_per_call": b_proj, "traffic": traffic,
+                             "traffic_source": ("%s (k_project_deep only; rocprofv3 PMC passes, NOT measured in this "
+                                                "run)" % tsrc) if tsrc else None,
+                             "k_project_deep_alone_GBps": (deep_bytes + VIEWS * 4 * 512 * (H // 2) * (W // 2)) /
+                                                          (k_ms["project_deep"] * 1e-3) / 1e9}}
+    raise ValueError(name)
+
+
+def compare_with_cpu(scene, rb, projector, ret, want, nr, dev):
+    """max relative error of one GPU result against the CPU oracle's on the first nr rays.
+    The 16 importance samples are an inverse-CDF lookup of the coarse weights, and visibility is a hard
+    in-frustum test: a 1e-7 change of the coarse weights can move a sample across a CDF bin edge or across
+    the border of a source image (reference behaviour, any two platforms differ this way).  Rays whose
+    fine depths or visibility masks differ between the GPU run and the CPU run are counted and left out
+    of the fine-level comparison."""
+    import oracle
+    from gp_nerf_amd import render_ray as rr
+    rbc = {k: v.cpu() for k, v in rb.items()}
+    rbc["ray_o"], rbc["ray_d"] = rbc["ray_o"][:nr], rbc["ray_d"][:nr]
+    _, zc = oracle.sampling.sample_along_camera_ray(rbc["ray_o"], rbc["ray_d"], rbc["depth_range"],
+                                                    N_SAMPLES, inv_uniform=True, det=True)
+    zf = [oracle.sampling.sample_fine_pts(True, N_IMPORTANCE, True, N_SAMPLES, rbc, w.clone(), zc)[1]
+          for w in (ret["outputs_coarse"]["weights"][:nr].cpu(), want["outputs_coarse"]["weights"])]
+    same = ((zf[0] - zf[1]).abs().amax(-1) <= 1e-4 * zf[1].abs().amax(-1))
+    # visibility of the fine samples: the GPU pipeline's own points vs the oracle's
+    sv = projector.prepare(rb["camera"], rb["src_rgbs"], rb["src_cameras"], scene.featmaps, scene.deep)
+    rbg = dict(rb)
+    rbg["ray_o"], rbg["ray_d"] = rb["ray_o"][:nr], rb["ray_d"][:nr]
+    pg, _ = rr.sample_fine_pts(True, N_IMPORTANCE, True, N_SAMPLES, rbg,
+                               ret["outputs_coarse"]["weights"][:nr], zc.to(dev))
+    m_gpu = (projector.compute_fused(pg, sv)[2].reshape(nr, -1, VIEWS) != 0).cpu()
+    pc, _ = oracle.sampling.sample_fine_pts(True, N_IMPORTANCE, True, N_SAMPLES, rbc,
+                                            want["outputs_coarse"]["weights"].clone(), zc)
+    pix, front = oracle.projector.compute_projections(pc, rbc["src_cameras"][0])
+    m_cpu = (oracle.projector.inbound(pix, float(scene.H), float(scene.W)) & front).permute(1, 2, 0)
+    same &= (m_gpu == m_cpu).reshape(nr, -1).all(dim=-1)
+    worst = 0.0
+    for lvl in ("outputs_coarse", "outputs_fine"):
+        for k in ("rgb", "depth", "weights", "feats_out"):
+            x, y = ret[lvl][k][:nr].cpu(), want[lvl][k]
+            if lvl == "outputs_fine":
+                x, y = x[same], y[same]
+            worst = max(worst, float((x - y).abs().max() / max(1.0, float(y.abs().max()))))
+    return worst, int((~same).sum())
 
 
 if __name__ == "__main__":

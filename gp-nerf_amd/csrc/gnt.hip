@@ -418,12 +418,14 @@ k_vis_scatter(const float* __restrict__ mask, int N, int V, int* __restrict__ cu
 //   Wq, Wk, Wv, Wo [64][68] | pos2 [64][20] | attn0 [16][68] | attn2 [64][20] | pos0 [16][4]
 //   | b_pos0[16] b_pos2[64] b_attn0[16] b_attn2[64] b_out[64] gamma[64] beta[64]
 #define VA_LD8 20
+#define VA_LDAF 100  // fp32 image of the folded [16][96] matrix (A0 Wk | A0 P2 | 0): 96 columns + 4 pad
 struct ViewLds {
   float *Wq, *Wk, *Wv, *Wo, *P2, *A0, *A2, *P0, *bP0, *bP2, *bA0, *bA2, *bO, *gam, *bet;
   float *AF, *c0;  // folded mode: (A0 Wk | A0 P2) image and the constant A0 b_pos2 + b_attn0
 };
 template <bool SPL>
 __device__ __forceinline__ ViewLds view_lds(float* s) {
+  static_assert(16 * VA_LDAF <= 64 * LDW, "the fp32 folded image must fit the unused Wk slot");
   ViewLds L;
   L.Wq = s;
   L.Wk = L.Wq + wimg_floats(SPL, 64, 4, LDW);
@@ -441,7 +443,8 @@ __device__ __forceinline__ ViewLds view_lds(float* s) {
   L.gam = L.bO + 64;
   L.bet = L.gam + 64;
   L.c0 = L.bet + 64;
-  L.AF = L.c0 + 16;
+  // split mode: its own slot behind the vectors; fp32 mode: the Wk slot (k itself is never formed when folded)
+  L.AF = SPL ? L.c0 + 16 : L.Wk;
   return L;
 }
 constexpr int view_lds_floats(bool spl) {
@@ -490,7 +493,6 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (tile loop, LDS-DMA base)
   STAMP(0);
-  static_assert(SPL || !FOLD, "the folded algorithm exists in split mode only");
   // Everything the first tile needs from global memory is requested BEFORE / WHILE the weights are
   // staged: slot -> point lookups first, then the weight loads, then the first two ring fills and
   // the q rows; their latencies run under the LDS stores and the barrier instead of after it.
@@ -670,7 +672,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
     sq.store(L.Wq, LDW, tid);
     if constexpr (FOLD) {
       sv.store(L.Wv, LDW, tid);
-      saf.store(L.AF, 0, tid);
+      saf.store(L.AF, VA_LDAF, tid);
       vc0.store(L.c0, tid);
     } else {
       sk.store(L.Wk, LDW, tid);
@@ -795,7 +797,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
         // pos hidden layer: 4 -> 8 (ReLU), one fp32 MFMA
         f4 ph = f4_relu_t<SPL>(mfma16(p0w, rd, ld4(L.bP0 + 4 * g)));
         f4 ah;  // post-ReLU hidden layer of attn_fc: rows 4g..4g+3 of the (zero-padded) 16
-        if constexpr (FOLD) {
+        if constexpr (FOLD && SPL) {
           // v + pos = (Wv Wk) f + P2 h + b ; attn hidden = (A0 Wk) f + (A0 P2) h + aq : every product
           // reads the split of f and h made once here
           XS xs[3];
@@ -808,6 +810,15 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
           lin_Sx<6, 1>(L.AF, xs, &ah, lane);
           ah = f4_relu_t<SPL>(ah);
           lin<SPL, 1, 4>(L.A2, VA_LD8, &ah, a, lane);
+        } else if constexpr (FOLD) {
+          // the same two chains on fp32 MFMAs: 117 instead of 177 MFMAs per (tile, view) -- k is never formed
+          const f4 xin[5] = {fcur[0], fcur[1], fcur[2], fcur[3], ph};  // K = 64 feature channels + 16 (8) hidden
+          lin_T<4, 4>(L.Wv, LDW, fcur, vp, lane);
+          lin_T<1, 4>(L.P2, VA_LD8, &ph, vp, lane);
+          ah = aq;
+          lin_T<5, 1>(L.AF, VA_LDAF, xin, &ah, lane);
+          ah = f4_relu_t<SPL>(ah);
+          lin_T<1, 4>(L.A2, VA_LD8, &ah, a, lane);
         } else {
           f4 k[4];
 #pragma unroll
@@ -2096,19 +2107,23 @@ extern "C" int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const
               "gpn_view_attn: stats_ld must be a multiple of 4 and >= %d (got %d)", C64, stats_ld);
   GPN_REQUIRE_INT_RANGE(N, 1, V, "gpn_view_attn");
   const bool spl = precision == GPN_PREC_BF16X3;
-  const bool fold = spl && L->folded != nullptr;
+  const bool fold = L->folded != nullptr;
   const size_t lds = sizeof(float) * view_lds_floats(spl) + (VA_TPB / 64) * 2 * VA_SLOT_BYTES;
-  const void* fn = fold ? reinterpret_cast<const void*>(k_view_attn<true, true>)
-                        : spl ? reinterpret_cast<const void*>(k_view_attn<true, false>)
-                              : reinterpret_cast<const void*>(k_view_attn<false, false>);
+  const void* fn = spl ? (fold ? reinterpret_cast<const void*>(k_view_attn<true, true>)
+                               : reinterpret_cast<const void*>(k_view_attn<true, false>))
+                       : (fold ? reinterpret_cast<const void*>(k_view_attn<false, true>)
+                               : reinterpret_cast<const void*>(k_view_attn<false, false>));
   int rc = set_lds_limit(fn, lds);
   if (rc) return rc;
   const int grid = persistent_grid(((long long)N + (VA_TPB / 4) - 1) / (VA_TPB / 4));
   GpnStageTimer timer_k_view_attn_(GPN_ST_VIEW_ATTN, (hipStream_t)stream);
   const dim3 g3(grid), b3(VA_TPB);
   hipStream_t st = (hipStream_t)stream;
-  if (fold)
+  if (fold && spl)
     hipLaunchKernelGGL((k_view_attn<true, true>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
+                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld);
+  else if (fold)
+    hipLaunchKernelGGL((k_view_attn<false, true>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
                        (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld);
   else if (spl)
     hipLaunchKernelGGL((k_view_attn<true, false>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,

@@ -159,6 +159,60 @@ def tile_layout(N_samples, N_importance, ret_alpha, has_semantics, gather_weight
     return out
 
 
+def render_rank_tiles(rank, G, ray_sampler, ray_batch, model, projector, chunk_size, N_samples,
+                      inv_uniform=False, N_importance=0, det=False, white_bkgd=False, render_stride=1,
+                      featmaps=None, deep_semantics=None, ret_alpha=False, single_net=False,
+                      gather_weights=False, render_fn=None, split_feats=False):
+    """The rank-local half of render_image_sharded: render rows [rank*rows, (rank+1)*rows) of the
+    strided grid and pack them into equal-size tiles, zero-padded (a rank without rows returns all
+    zeros).  -> (layout, tiles): tiles[level] = None (level absent) or a dict with 'shared'
+    [rows*W', sum of the shared columns] and, with split_feats, 'feats' [rows*W', 512]."""
+    Hs, Ws = _strided_hw(ray_sampler, render_stride)
+    rows, parts = shard_rows(Hs, G)
+    r0, r1 = parts[rank]
+    fn = render_fn or _render_chunks
+    acc = fn(ray_batch, model, projector, chunk_size, N_samples, inv_uniform, N_importance, det,
+             white_bkgd, featmaps, deep_semantics, ret_alpha, single_net, r0 * Ws, r1 * Ws, False)
+    dev = ray_batch["ray_o"].device
+    layout = tile_layout(N_samples, N_importance, ret_alpha, deep_semantics is not None, gather_weights)
+    tiles = OrderedDict()
+    for lvl, cols in layout.items():
+        if cols is None:
+            tiles[lvl] = None
+            continue
+
+        def build(spec):
+            tile = torch.zeros((rows * Ws, sum(w for _, w in spec)), device=dev)
+            if r1 > r0:
+                pieces = []
+                for k, w in spec:
+                    t = torch.cat(acc[lvl][k], dim=0)
+                    t = t.reshape(t.shape[0], -1)
+                    if tuple(t.shape) != ((r1 - r0) * Ws, w):
+                        raise RuntimeError("rank %d: %s/%s has shape %s, the tile layout expects [%d, %d]"
+                                           % (rank, lvl, k, tuple(t.shape), (r1 - r0) * Ws, w))
+                    pieces.append(t)
+                tile[: (r1 - r0) * Ws] = torch.cat(pieces, dim=1)
+            return tile
+
+        apart = split_feats and any(k == "feats_out" for k, _ in cols)
+        shared = [(k, w) for k, w in cols if not (apart and k == "feats_out")]
+        tiles[lvl] = {"shared": build(shared), "shared_cols": shared,
+                      "feats": build([("feats_out", 512)]) if apart else None}
+    return layout, tiles
+
+
+def merge_rank_tiles(cols, full, Hs, Ws):
+    """Rank-ordered concatenation of equal-size tiles [G*rows*W', width] -> {key: [H',W',.]} (the
+    padding rows of the last ranks are cut off)."""
+    full = full[: Hs * Ws]
+    out, o = OrderedDict(), 0
+    for k, wdt in cols:
+        out[k] = full[:, o:o + wdt].reshape(Hs, Ws, wdt).squeeze()
+        o += wdt
+    return out
+
+
 def render_image_sharded(ray_sampler, ray_batch, model, projector, chunk_size, N_samples,
                          inv_uniform=False, N_importance=0, det=False, white_bkgd=False,
                          render_stride=1, featmaps=None, deep_semantics=None, ret_alpha=False,
@@ -181,57 +235,32 @@ def render_image_sharded(ray_sampler, ray_batch, model, projector, chunk_size, N
     multi = dist.is_initialized()
     G = dist.get_world_size(group) if multi else 1
     rank = dist.get_rank(group) if multi else 0
-    Hs, Ws = _strided_hw(ray_sampler, render_stride)
-    rows, parts = shard_rows(Hs, G)
-    r0, r1 = parts[rank]
-    fn = render_fn or _render_chunks
-    acc = fn(ray_batch, model, projector, chunk_size, N_samples, inv_uniform, N_importance, det,
-             white_bkgd, featmaps, deep_semantics, ret_alpha, single_net, r0 * Ws, r1 * Ws, False)
-    dev = ray_batch["ray_o"].device
-    layout = tile_layout(N_samples, N_importance, ret_alpha, deep_semantics is not None, gather_weights)
+    root = dist.get_global_rank(group, 0) if (multi and group is not None) else 0
     if labels_only and sem_head is None:
         raise ValueError("labels_only=True needs a sem_head")
+    Hs, Ws = _strided_hw(ray_sampler, render_stride)
+    layout, tiles = render_rank_tiles(
+        rank, G, ray_sampler, ray_batch, model, projector, chunk_size, N_samples, inv_uniform,
+        N_importance, det, white_bkgd, render_stride, featmaps, deep_semantics, ret_alpha, single_net,
+        gather_weights, render_fn, split_feats=labels_only)
+    dev = ray_batch["ray_o"].device
     out = OrderedDict()
     for lvl, cols in layout.items():
         if cols is None:
             out[lvl] = None
             continue
-        # features travel separately (to rank 0 only) in labels_only mode
-        split_feats = labels_only and any(k == "feats_out" for k, _ in cols)
-        shared = [(k, w) for k, w in cols if not (split_feats and k == "feats_out")]
-
-        def build(spec):
-            tile = torch.zeros((rows * Ws, sum(w for _, w in spec)), device=dev)
-            if r1 > r0:
-                parts_ = []
-                for k, w in spec:
-                    t = torch.cat(acc[lvl][k], dim=0)
-                    t = t.reshape(t.shape[0], -1)
-                    if t.shape != ((r1 - r0) * Ws, w):
-                        raise RuntimeError("rank %d: %s/%s has shape %s, the tile layout expects [%d, %d]"
-                                           % (rank, lvl, k, tuple(t.shape), (r1 - r0) * Ws, w))
-                    parts_.append(t)
-                tile[: (r1 - r0) * Ws] = torch.cat(parts_, dim=1)
-            return tile
-
-        tile = build(shared)
+        tile = tiles[lvl]["shared"]
         if G > 1:
-            full = torch.empty((G * rows * Ws, tile.shape[1]), device=dev)
+            full = torch.empty((G * tile.shape[0], tile.shape[1]), device=dev)
             dist.all_gather_into_tensor(full, tile, group=group)
         else:
             full = tile
-        full = full[: Hs * Ws]
-        out[lvl] = OrderedDict()
-        o = 0
-        for k, wdt in shared:
-            out[lvl][k] = full[:, o:o + wdt].reshape(Hs, Ws, wdt).squeeze()
-            o += wdt
-        if split_feats:
-            ftile = build([("feats_out", 512)])
+        out[lvl] = merge_rank_tiles(tiles[lvl]["shared_cols"], full, Hs, Ws)
+        ftile = tiles[lvl]["feats"]
+        if ftile is not None:  # labels_only: the feature tiles go to rank 0 only
             if G > 1:
                 bufs = [torch.empty_like(ftile) for _ in range(G)] if rank == 0 else None
-                dist.gather(ftile, bufs, dst=dist.get_global_rank(group, 0) if group is not None else 0,
-                            group=group)
+                dist.gather(ftile, bufs, dst=root, group=group)
                 if rank == 0:
                     out[lvl]["feats_out"] = torch.cat(bufs, dim=0)[: Hs * Ws].reshape(Hs, Ws, 512)
             else:
@@ -247,7 +276,6 @@ def render_image_sharded(ray_sampler, ray_batch, model, projector, chunk_size, N
                 hh, ww = (len(range(0, Hs, 2)), len(range(0, Ws, 2))) if render_stride == 1 else (Hs, Ws)
                 if lab is None:
                     lab = torch.empty((2 * hh, 2 * ww), dtype=torch.uint8, device=dev)
-                dist.broadcast(lab, src=dist.get_global_rank(group, 0) if group is not None else 0,
-                               group=group)
+                dist.broadcast(lab, src=root, group=group)
             out[lvl]["labels"] = lab
     return out

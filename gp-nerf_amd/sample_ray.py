@@ -18,22 +18,23 @@ from . import _lib
 rng = np.random.RandomState(234)  # reference sample_ray.py:6 (module-level, same seed)
 
 
+def _split_camera(params, k_side, pose_rows):
+    """Rows of [H, W, K (k_side x k_side, row-major), pose (pose_rows x 4, row-major)] ->
+    (W, H, K [B,k,k], pose [B,rows,4]) -- the tuple order of the reference's parsers."""
+    nk = k_side * k_side
+    K = params[:, 2:2 + nk].reshape((-1, k_side, k_side))
+    pose = params[:, 2 + nk:2 + nk + 4 * pose_rows].reshape((-1, pose_rows, 4))
+    return params[:, 1], params[:, 0], K, pose
+
+
 def parse_camera(params):
-    """23-float cameras (reference :13-18)."""
-    H = params[:, 0]
-    W = params[:, 1]
-    intrinsics = params[:, 2:11].reshape((-1, 3, 3))
-    c2w = params[:, 11:23].reshape((-1, 3, 4))
-    return W, H, intrinsics, c2w
+    """23-float cameras: 3x3 intrinsics, 3x4 pose (reference sample_ray.py:13-18)."""
+    return _split_camera(params, 3, 3)
 
 
 def parse_camera_ray(params):
-    """34-float cameras [H, W, K(4x4), c2w(4x4)] (reference :20-25)."""
-    H = params[:, 0]
-    W = params[:, 1]
-    intrinsics = params[:, 2:18].reshape((-1, 4, 4))
-    c2w = params[:, 18:34].reshape((-1, 4, 4))
-    return W, H, intrinsics, c2w
+    """34-float cameras: 4x4 intrinsics, 4x4 pose (reference sample_ray.py:20-25)."""
+    return _split_camera(params, 4, 4)
 
 
 def _dev(t, device):
@@ -141,21 +142,20 @@ class RaySamplerSingleImage(object):
         }
 
     def sample_random_pixel(self, N_rand, sample_mode, center_ratio=0.8):
-        """reference :149-170 (host-side index choice with the module's RandomState)."""
-        if sample_mode == "center":
-            border_H = int(self.H * (1 - center_ratio) / 2.0)
-            border_W = int(self.W * (1 - center_ratio) / 2.0)
-            u, v = np.meshgrid(np.arange(border_H, self.H - border_H),
-                               np.arange(border_W, self.W - border_W))
-            u = u.reshape(-1)
-            v = v.reshape(-1)
-            select_inds = rng.choice(u.shape[0], size=(N_rand,), replace=False)
-            select_inds = v[select_inds] + self.W * u[select_inds]
-        elif sample_mode == "uniform":
-            select_inds = rng.choice(self.H * self.W, size=(N_rand,), replace=False)
-        else:
+        """Flat pixel indices of N_rand distinct pixels, drawn with the module's RandomState exactly as
+        reference sample_ray.py:149-170 draws them (same stream, same values): 'uniform' over the image,
+        'center' over the window that leaves a margin of (1 - center_ratio)/2 on every side."""
+        if sample_mode == "uniform":
+            return rng.choice(self.H * self.W, size=(N_rand,), replace=False)
+        if sample_mode != "center":
             raise Exception("unknown sample mode!")
-        return select_inds
+        top = int(self.H * (1 - center_ratio) / 2.0)
+        left = int(self.W * (1 - center_ratio) / 2.0)
+        n_rows, n_cols = self.H - 2 * top, self.W - 2 * left
+        # the reference numbers the window's pixels column by column (np.meshgrid of (rows, cols) in
+        # 'xy' order, flattened): candidate k is row top + k % n_rows, column left + k // n_rows
+        k = rng.choice(n_rows * n_cols, size=(N_rand,), replace=False)
+        return (left + k // n_rows) + self.W * (top + k % n_rows)
 
     def random_sample(self, N_rand, sample_mode, center_ratio=0.8):
         """reference :172-214: N_rand rays of the image (indices chosen on the host as in the

@@ -121,7 +121,44 @@ def test_projector_bit_exact(dev, golden):
     assert np.array_equal(mask.cpu().numpy(), g["mask"])
     assert np.array_equal(rgb_feat.cpu().numpy(), g["rgb_feat"])
     assert np.array_equal(deep[:8].cpu().numpy(), g["deep_head"])
+    # every ray's 512-channel rows against the reference: the fp64 channel sums of bit-identical
+    # values are bit-identical (rays beyond the first 8 are not stored whole in the fixture)
+    assert np.array_equal(deep.double().sum(dim=-1).cpu().numpy(), g["deep_sum"])
     assert rel(ray_diff, g["ray_diff"]) < 1e-5
+
+
+def test_projector_reused_across_images(dev):
+    """One Projector serves every image of an eval loop (reference eval_gpnerf.py:97-118).  The camera
+    tensors of successive images have the same shape and _version 0, and the caching allocator hands a
+    freed 512-byte block straight back: the Projector's caches must not take image B's cameras for image
+    A's.  Renders scene A, frees its tensors, renders scene B (other rig) and compares B with the oracle."""
+    import gc
+    from gp_nerf_amd import synth
+    from gp_nerf_amd.projection import Projector
+    P = Projector(dev)
+    K = synth.scaled_intrinsics(synth.SCANNET_K, 0.2, 0.2)
+    ptrs = []
+    for seed, rig in ((11, dict(dx=0.05, dy=0.01, yaw_deg=-1.0)), (12, dict(dx=0.3, dy=-0.08, yaw_deg=4.0)),
+                      (13, dict(dx=-0.2, dy=0.05, yaw_deg=-6.0))):
+        sc = synth.Scene(48, 64, 4, K, (0.1, 6.0), seed=seed, rig=rig)
+        rb = sc.ray_batch(start=500, count=32)
+        pts = (rb["ray_o"][:, None] + rb["ray_d"][:, None] * torch.linspace(0.3, 4.0, 12)[None, :, None]).contiguous()
+        cam, cams = rb["camera"].to(dev), rb["src_cameras"].to(dev)  # fresh device tensors per image, as get_all() makes
+        ptrs.append((cam.data_ptr(), cams.data_ptr()))
+        got = P.compute(pts.to(dev), cam, rb["src_rgbs"].to(dev), cams, sc.featmaps.to(dev), sc.deep_semantics.to(dev))
+        want = oracle.projector.compute(pts, rb["camera"], rb["src_rgbs"], rb["src_cameras"], sc.featmaps,
+                                        sc.deep_semantics)
+        for nm, a, b in zip(("rgb_feat", "deep", "ray_diff", "mask"), got, want):
+            if nm == "ray_diff":
+                # (unit(a - b) of two nearly parallel unit vectors: 5 cm baselines at 4 m amplify the fp32
+                # rounding of a and b a hundredfold, so the direction carries ~1e-5; a stale camera gives O(1))
+                assert rel(a, b) < 1e-4, "image seed %d: %s" % (seed, nm)
+            else:
+                assert torch.equal(a.cpu(), b), "image seed %d: %s differs (stale camera cache?)" % (seed, nm)
+        del cam, cams, got, rb, sc
+        gc.collect()
+    # (informational: with the fix the cache keeps the old tensors alive, so addresses do not repeat)
+    assert len(set(ptrs)) == len(ptrs), "camera tensors were recycled while the cache still keyed on them"
 
 
 def test_projector_taps_and_helpers(dev):
@@ -228,11 +265,21 @@ def test_samplers(dev, golden):
         want = oracle.sampling.sample_pdf(bins, wsel, 16, det=True)
         got = rr.sample_pdf(bins.to(dev), wsel.to(dev).contiguous(), 16, det=True).cpu()
         denom, width = _pdf_reference(bins, wsel, u16)
-        _check_pdf_samples(got, want, denom, width, float(bins.abs().max()))
-        # merged + sorted list vs the golden run: well-conditioned rays to 1e-5
+        # merged + sorted list vs the golden run (the reference itself).  Rays whose every sample sits in
+        # a well-conditioned bin (denominator > 2e-3: fp32 cdf noise amplified to < 1e-5 of the range) must
+        # match to 1e-5; on the others the un-reproducible reduction order of torch.sum decides the last
+        # bits, so they are held to the conditioning-aware bound per sample instead.
+        n_edge = _check_pdf_samples(got, want, denom, width, float(bins.abs().max()))
         good = (denom.min(dim=-1)[0] > 2e-3).numpy()
-        assert good.sum() >= 3
+        gz = torch.from_numpy(g["fz_" + tag])
+        per_ray = ((fzc - gz).abs().amax(-1) / gz.abs().amax()).numpy()
+        frac_good, frac_close = float(good.mean()), float((per_ray < 1e-5).mean())
+        print("sample_fine_pts[%s]: %d/%d rays well-conditioned, %.1f%% of ALL rays within 1e-5 of the "
+              "reference's golden depths, %d knife-edge samples exempted" %
+              (tag, int(good.sum()), good.size, 100 * frac_close, n_edge))
         assert rel(fzc[good], g["fz_" + tag][good]) < 1e-5
+        assert frac_close >= 0.8, "only %.0f%% of the rays match the golden fine depths to 1e-5" % (100 * frac_close)
+        assert n_edge <= 0.02 * got.numel(), "too many knife-edge exemptions (%d)" % n_edge
         merged = torch.sort(torch.cat([zc, (1.0 / got) if inv else got], -1), -1)[0]
         assert rel(fzc, merged) < 1e-6
     # stochastic paths: same formulas with injected randoms
@@ -685,20 +732,28 @@ def test_render_rays_stress_shape(dev, net, prec):
 
 
 # ------------------------------------------------------------------------------ ray generation (8(f) rank 1)
-def test_full_size_properties(dev):
+@pytest.mark.parametrize("rig,mode", [("sparse", "bf16x3"), ("dense", "fp32")])
+def test_full_size_properties(dev, rig, mode):
     """BASELINE.json configs[1] at full size (4096 rays, 48 + 16 samples, 10 views, 640x480 maps: too big
     for the CPU oracle in a test) through size-independent properties of the path:
     * chunk invariance: the 4096-ray chunk equals its two ragged halves rendered separately, bit for bit
       (reference render_image.py:39-62 relies on rays being independent);
     * every attention-weight row is a distribution (sums to 1), everything finite;
     * linearity in the deep-semantic maps: doubling the maps doubles feats_out_3d
-      exactly and leaves rgb / weights / depth untouched bit for bit."""
+      exactly and leaves rgb / weights / depth untouched bit for bit.
+    Both visibility regimes of the bench: the sparse rig (~41 % of the pairs visible,
+    most tiles skip views) and the dense rig (~96 %, nearly every view computed), one arithmetic mode each."""
     import bench
     from gp_nerf_amd.render_ray import render_rays
-    scene, gnt, projector = bench.build(dev)
-    gnt.precision = "bf16x3"
+    scene, gnt, projector = bench.build(dev, rig=rig)
+    gnt.precision = mode
     model = types.SimpleNamespace(net_coarse=gnt, net_fine=None)
     rb = bench.ray_chunk(scene, 0, 1, dev)
+    sv = projector.prepare(rb["camera"], rb["src_rgbs"], rb["src_cameras"], scene.featmaps, scene.deep)
+    from gp_nerf_amd import render_ray as rr
+    pts0, _ = rr.sample_along_camera_ray(rb["ray_o"], rb["ray_d"], rb["depth_range"], 48, inv_uniform=True, det=True)
+    vis_mean = float(projector.compute_fused(pts0, sv)[2].mean())
+    assert (vis_mean > 0.9) if rig == "dense" else (0.3 < vis_mean < 0.6), vis_mean
 
     def run(batch, deep):
         return render_rays(batch, model, scene.featmaps, deep, projector, N_samples=48, inv_uniform=True,
@@ -911,3 +966,81 @@ def test_checkpoint_roundtrip_and_render_view(dev, tmp_path):
     top2 = lg[0].topk(2, dim=0).values
     clear = (top2[0] - top2[1]) > 1e-2 * lg.abs().max()
     assert torch.equal(ret["outputs_coarse"]["labels"].cpu()[clear], lg[0].argmax(dim=0)[clear])
+
+
+def test_sem_head_direct_vs_oracle(dev):
+    """a15 at the reference's own size: device head vs the CPU restatement on a [1,512,120,160] feature
+    image, 21 classes (reference semantic_branch.py:89-107; 120x160 is hard-coded there, :95).  Logits
+    within 1e-4 of the tensor scale; the label image agrees wherever the oracle's top-2 margin exceeds
+    the logit error, and the margin histogram quantifies how many pixels could flip at all.
+    PARITY UNPINNED against the reference itself (detectron2 / fvcore absent, no fixture): this pins
+    the device module to the restatement only."""
+    from gp_nerf_amd import synth
+    from gp_nerf_amd.semantic_branch import NeRFSemSegFPNHead
+    sd = synth.hashed_state_dict(synth.sem_head_param_shapes(), 901)
+    head = NeRFSemSegFPNHead(types.SimpleNamespace(), num_classes=20)
+    head.load_state_dict(sd, strict=True)
+    head = head.to(dev).eval()
+    x = torch.from_numpy(synth.hash_normal(31, 7, (1, 512, 120, 160)))
+    want = oracle.sem_head.forward(sd, x)
+    got = head(x.to(dev))
+    assert tuple(got.shape) == (1, 21, 240, 320)
+    err_abs = float((got.cpu() - want).abs().max())
+    err = rel(got, want)
+    labels = head.labels(x.to(dev)).cpu()
+    assert torch.equal(labels, got.cpu().permute(0, 2, 3, 1).argmax(dim=-1)[0])
+    top2 = want[0].topk(2, dim=0).values
+    margin = top2[0] - top2[1]
+    edges = [0.0, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2, float("inf")]
+    hist = [int(((margin >= lo) & (margin < hi)).sum()) for lo, hi in zip(edges[:-1], edges[1:])]
+    agree = labels == want[0].argmax(dim=0)
+    print("sem head: logits rel err %.2e (abs %.2e); top-2 margin histogram %s over bins %s; labels agree on "
+          "%d / %d pixels" % (err, err_abs, hist, edges, int(agree.sum()), agree.numel()))
+    assert err < TOL, err
+    clear = margin > 4 * err_abs
+    assert bool(agree[clear].all()), "a label differs where the oracle's top-2 margin exceeds the logit error"
+    assert float(clear.float().mean()) > 0.99, "margins too small to say anything about the labels"
+
+
+@pytest.mark.parametrize("G", [2, 4])
+def test_rank_count_invariance_real_renderer(dev, net, G):
+    """north_star (4): the image is the same bits for 1, 2 and 4 ranks.  The rank-local half of
+    render_image_sharded (render_rank_tiles: real renderer, real tile packing) is run for every rank of
+    a G-rank job on this one GPU, the tiles are concatenated in rank order -- what all_gather_into_tensor
+    does, tests/test_cpu_host.py covers the collective itself on gloo -- and merged; the result must
+    equal the 1-rank image bit for bit.  H' = 9 with G = 4: rows per rank 3, the last rank owns none."""
+    from gp_nerf_amd import render_image as ri
+    from gp_nerf_amd.projection import Projector
+    net.precision = "bf16x3"
+    c = cases.g5_render_image()
+    Hh, Ww = 9, c["W"]
+    rb = to(dev, c["ray_batch"])
+    rb["ray_o"], rb["ray_d"] = rb["ray_o"][: Hh * Ww].contiguous(), rb["ray_d"][: Hh * Ww].contiguous()
+    sampler = types.SimpleNamespace(H=Hh, W=Ww)
+    P = Projector(dev)
+    kw = dict(inv_uniform=True, N_importance=8, det=True, render_stride=1, featmaps=c["featmaps"].to(dev),
+              deep_semantics=c["deep_semantics"].to(dev), ret_alpha=True, single_net=True, gather_weights=True)
+
+    def image(world):
+        per_rank = [ri.render_rank_tiles(k, world, sampler, rb, _model(net), P, 50, 16, **kw) for k in range(world)]
+        layout = per_rank[0][0]
+        out = {}
+        for lvl, cols in layout.items():
+            full = torch.cat([t[lvl]["shared"] for _, t in per_rank], dim=0)
+            out[lvl] = ri.merge_rank_tiles(per_rank[0][1][lvl]["shared_cols"], full, Hh, Ww)
+        return out
+
+    one, many = image(1), image(G)
+    rows, parts = ri.shard_rows(Hh, G)
+    if G == 4:
+        assert parts[-1][0] == parts[-1][1], "the case is meant to leave the last rank without rows"
+    for lvl in ("outputs_coarse", "outputs_fine"):
+        assert set(one[lvl]) == {"rgb", "depth", "feats_out", "weights"}
+        for k in one[lvl]:
+            assert torch.equal(one[lvl][k].view(torch.int32), many[lvl][k].view(torch.int32)), (G, lvl, k)
+    # and the sharded entry point itself, outside a process group (world 1), returns the same image
+    solo = ri.render_image_sharded(sampler, rb, _model(net), P, 50, 16, **kw)
+    for lvl in ("outputs_coarse", "outputs_fine"):
+        for k in one[lvl]:
+            assert torch.equal(solo[lvl][k], one[lvl][k]), (lvl, k)
+    net.precision = "fp32"

@@ -95,6 +95,8 @@ _SIGS = {
     "gpn_argmax_labels": (C.c_int, [_P, C.c_int, C.c_longlong, _P, _P, _P]),
     "gpn_repack_nhwc": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "gpn_project_gather": (C.c_int, [C.POINTER(ProjectArgs), _P]),
+    "gpn_project_rgbfeat": (C.c_int, [C.POINTER(ProjectArgs), C.POINTER(Linear), C.POINTER(Linear), _P, _P,
+                                      C.c_int, _P]),
     "gpn_posenc": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "gpn_rgbfeat": (C.c_int, [C.POINTER(Linear), C.POINTER(Linear), _P, C.c_int, C.c_int, C.c_int,
                               C.c_int, _P, _P, _P, C.c_int, _P]),
@@ -114,6 +116,8 @@ _SIGS = {
     "gpn_gnt_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "gpn_gnt_forward": (C.c_int, [C.POINTER(GntWeights), _P, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int,
                                   C.c_int, C.POINTER(SemArgs), _P, _P, _P, _P, C.c_size_t, _P]),
+    "gpn_render_pass": (C.c_int, [C.POINTER(GntWeights), C.POINTER(ProjectArgs), _P, _P, _P, C.c_int, C.c_int,
+                                  C.POINTER(SemArgs), _P, _P, _P, _P, C.c_size_t, _P]),
     "gpn_gnt_forward_static": (C.c_int, [C.POINTER(GntWeights), _P, C.c_int, _P, _P, _P, _P, _P, C.c_int,
                                          C.c_int, C.c_int, C.POINTER(SemArgs), _P, _P, _P, _P]),
     "gpn_timing_begin": (C.c_int, [C.c_uint, C.c_int]),
@@ -121,7 +125,7 @@ _SIGS = {
 }
 
 STAGES = ("sample", "project", "project_deep", "posenc", "rgbfeat", "view_attn", "ff", "qpos",
-          "ray_attn", "sem", "heads", "vis_order")
+          "ray_attn", "sem", "heads", "vis_order", "proj_rgbfeat")
 
 EXPORTS = tuple(_SIGS)
 _lib = None

@@ -308,6 +308,219 @@ k_rgbfeat(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ rgb_feat
   }
 }
 
+// ------------------------------------------------------------------------------------ fused projector + rgbfeat
+// The fast path of render_rays: projection.py:31-139 (RGB + 32-channel gather, masks, ray_diff) and
+// transformer_network.py:309-311 (rgbfeat_fc, max over views) in ONE kernel -- the [N,V,35] tensor between
+// them (330 MB written and read back per 64-sample pass) never exists, and the pairs whose gathered row is
+// exactly zero (every bilinear tap outside both maps: ~half of the pairs of an indoor rig) cost neither a
+// gather nor an MLP evaluation: their feature row is the constant c0 = fc2(relu(fc0.bias)) + bias.
+// Same T-tile scheme as k_rgbfeat (16 points per wave-tile).  Per tile:
+//   pre-pass  lane (j, g) projects point j into views g, g+4, ...: mask bits of every view (written out),
+//             vis = the point's visibility word, wr = the views whose feature rows gpn_view_attn will read
+//             (the visible ones; every view when the point has no visible view at all)
+//   per group of 4 views
+//     phase 1 lane (j, g) does the per-pair arithmetic of (point j, view 4k+g) once: tap positions and
+//             bilinear weights on both maps -> a per-wave LDS table; ray_diff for the pairs in wr
+//     phase 2 per view: 4 lanes per point gather their channels straight from the NHWC maps (feature
+//             channels first, RGB last: fc0's columns are permuted to match when its image is staged),
+//             bilinear blend with the projector's fma chain (same bits as k_project_feat), MLP on MFMA,
+//             feature row stored if in wr, running maximum for q0 (over ALL views, as in the reference)
+// A point's results never depend on its tile mates, so chunking / rank count change no bits.
+#ifndef PR_TPB
+#define PR_TPB 256  // 146 VGPRs, ~45 KB of LDS: three workgroups (3 waves per SIMD) per CU
+#endif
+#ifndef PR_BPC
+#define PR_BPC 3
+#endif
+struct PrTab {  // per wave: 4 views x 16 points
+  int fx[64], fy[64], rx[64], ry[64];  // clamped tap columns / rows, (x1 << 16) | x0
+  float fw[4][64], rw[4][64];          // nw ne sw se; 0 for a tap outside the map
+};
+
+template <bool SPL>
+__global__ void __launch_bounds__(PR_TPB)
+k_proj_rgbfeat(gpn_project_args_t a, gpn_linear_t fc0, gpn_linear_t fc2, float* __restrict__ feat,
+               float* __restrict__ q0) {
+  float* W0 = smem;
+  float* W2 = W0 + wimg_floats(SPL, 64, 3, RF_LD0);
+  float* b0 = W2 + wimg_floats(SPL, 64, 4, LDW);
+  float* b2 = b0 + 64;
+  float* sP = b2 + 64;                      // [V][12]
+  float* sPos = sP + GPN_MAX_VIEWS * 12;    // [V][3]
+  PrTab* tabs = reinterpret_cast<PrTab*>(sPos + GPN_MAX_VIEWS * 3);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  PrTab& tab = tabs[wave];
+  const int V = a.V;
+  {
+    // fc0's image with the columns in gather order: [feature 0..31 | r g b | 0 ...]  (reference order: rgb first)
+    const int in_ch = 3 + a.feat_c;
+    if constexpr (SPL) {
+      bf8* dst = reinterpret_cast<bf8*>(W0);
+      for (int idx = tid; idx < 64 * 8; idx += PR_TPB) {  // 64 rows x (2 K pairs x 4 g)
+        const int row = idx >> 3, u = idx & 7, P = u >> 2, g = u & 3;
+        f4 x0 = f4_zero(), x1 = f4_zero();
+        const float* r = fc0.w + (size_t)row * in_ch;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c0 = 32 * P + 4 * g + e, c1 = c0 + 16;  // gather-order columns
+          x0[e] = c0 < 32 ? r[3 + c0] : (c0 < 35 ? r[c0 - 32] : 0.0f);
+          x1[e] = c1 < 32 ? r[3 + c1] : (c1 < 35 ? r[c1 - 32] : 0.0f);
+        }
+        const XS sp = split8(x0, x1);
+        const int blk = (((row >> 4) * 2 + P) * 2) * 64 + 16 * g + (row & 15);
+        dst[blk] = sp.hi;
+        dst[blk + 64] = sp.mid;
+      }
+    } else {
+      for (int idx = tid; idx < 64 * 48; idx += PR_TPB) {
+        const int row = idx / 48, c = idx - row * 48;
+        const float* r = fc0.w + (size_t)row * in_ch;
+        W0[row * RF_LD0 + c] = c < 32 ? r[3 + c] : (c < 35 ? r[c - 32] : 0.0f);
+      }
+    }
+    WStage<SPL, 64, 4, PR_TPB> s2;
+    VecStage<64, PR_TPB> v0, v2;
+    s2.load(fc2.w, 64, 64, tid);
+    v0.load(fc0.b, 64, tid), v2.load(fc2.b, 64, tid);
+    s2.store(W2, LDW, tid);
+    v0.store(b0, tid), v2.store(b2, tid);
+    for (int i = tid; i < V * 12; i += PR_TPB) sP[i] = a.proj[(i / 12) * 16 + (i % 12)];
+    for (int i = tid; i < V * 3; i += PR_TPB) sPos[i] = a.src_pos[i];
+  }
+  __syncthreads();
+  const int j = lane & 15, g = lane >> 4;
+  const long long N = a.N;
+  const long long ntiles = (N + 15) >> 4;
+  const long long tstride = (long long)gridDim.x * (PR_TPB / 64);
+  const unsigned all_views = V >= 32 ? 0xffffffffu : ((1u << V) - 1u);
+
+  // one MLP evaluation: x (3 T-tiles, gather order) -> y (4 T-tiles)
+  auto mlp = [&](const f4* x, f4* y) {
+    f4 h[4];
+#pragma unroll
+    for (int M = 0; M < 4; ++M) h[M] = ld4(b0 + 16 * M + 4 * g);
+    lin<SPL, 3, 4>(W0, RF_LD0, x, h, lane);
+#pragma unroll
+    for (int M = 0; M < 4; ++M) {
+      h[M] = f4_relu_t<SPL>(h[M]);
+      y[M] = ld4(b2 + 16 * M + 4 * g);
+    }
+    lin<SPL, 4, 4>(W2, LDW, h, y, lane);
+  };
+  auto store_row = [&](long long n, int v, const f4* y) {
+    float* row = feat + ((size_t)n * V + v) * C64;
+    if constexpr (SPL) {
+      store_feat_split(row, y, g);
+    } else {
+#pragma unroll
+      for (int M = 0; M < 4; ++M) st4(row + 16 * M + 4 * g, y[M]);
+    }
+  };
+  // the feature row of an all-zero input, by the same instruction sequence as any other row
+  f4 c0[4];
+  {
+    const f4 xz[3] = {f4_zero(), f4_zero(), f4_zero()};
+    mlp(xz, c0);
+  }
+  const int fw_ = a.feat_w, fh_ = a.feat_h, rw_ = a.rgb_w, rh_ = a.rgb_h;
+
+  for (long long tile = (long long)blockIdx.x * (PR_TPB / 64) + wave; tile < ntiles; tile += tstride) {
+    const long long n = tile * 16 + j;
+    const bool valid = n < N;
+    const long long nc = valid ? n : N - 1;
+    const float px = a.xyz[nc * 3 + 0], py = a.xyz[nc * 3 + 1], pz = a.xyz[nc * 3 + 2];
+    // ---- pre-pass: masks of every view
+    unsigned vis = 0;
+    for (int v = g; v < V; v += 4) {
+      const GpnPix pp = gpn_project(sP + v * 12, px, py, pz);
+      const bool m = pp.front && gpn_inbound(pp.px, pp.py, a.img_h, a.img_w);
+      if (valid) a.mask[(size_t)n * V + v] = m ? 1.0f : 0.0f;
+      vis |= (m ? 1u : 0u) << v;
+    }
+    vis |= __shfl_xor(vis, 16);
+    vis |= __shfl_xor(vis, 32);
+    const unsigned wr = valid ? (vis != 0 ? vis : all_views) : 0u;  // rows gpn_view_attn reads
+    f4 qmax[4];
+#pragma unroll
+    for (int M = 0; M < 4; ++M) qmax[M] = f4_splat(-INFINITY);
+
+    for (int vb = 0; vb < V; vb += 4) {
+      // ---- phase 1: lane (j, g) <-> pair (point j, view vb + g)
+      bool zero_row = true;
+      {
+        const int v = vb + g;
+        if (v < V) {
+          const GpnPix pp = gpn_project(sP + v * 12, px, py, pz);
+          const GpnTaps tf = gpn_taps(pp.px, pp.py, a.img_h, a.img_w, fh_, fw_);
+          const GpnTaps tr = gpn_taps(pp.px, pp.py, a.img_h, a.img_w, rh_, rw_);
+          const bool any_f = (tf.vx0 || tf.vx1) && (tf.vy0 || tf.vy1);
+          const bool any_r = (tr.vx0 || tr.vx1) && (tr.vy0 || tr.vy1);
+          zero_row = !valid || !(any_f || any_r);
+          auto cl = [](int c, int hi) { return min(max(c, 0), hi); };
+          tab.fx[lane] = cl(tf.x0, fw_ - 1) | (cl(tf.x0 + 1, fw_ - 1) << 16);
+          tab.fy[lane] = cl(tf.y0, fh_ - 1) | (cl(tf.y0 + 1, fh_ - 1) << 16);
+          tab.rx[lane] = cl(tr.x0, rw_ - 1) | (cl(tr.x0 + 1, rw_ - 1) << 16);
+          tab.ry[lane] = cl(tr.y0, rh_ - 1) | (cl(tr.y0 + 1, rh_ - 1) << 16);
+          tab.fw[0][lane] = (tf.vy0 && tf.vx0) ? tf.nw : 0.0f, tab.fw[1][lane] = (tf.vy0 && tf.vx1) ? tf.ne : 0.0f;
+          tab.fw[2][lane] = (tf.vy1 && tf.vx0) ? tf.sw : 0.0f, tab.fw[3][lane] = (tf.vy1 && tf.vx1) ? tf.se : 0.0f;
+          tab.rw[0][lane] = (tr.vy0 && tr.vx0) ? tr.nw : 0.0f, tab.rw[1][lane] = (tr.vy0 && tr.vx1) ? tr.ne : 0.0f;
+          tab.rw[2][lane] = (tr.vy1 && tr.vx0) ? tr.sw : 0.0f, tab.rw[3][lane] = (tr.vy1 && tr.vx1) ? tr.se : 0.0f;
+          if ((wr >> v) & 1u)  // dead pairs are never read by gpn_view_attn: their 9 divisions are skipped
+            *reinterpret_cast<float4*>(a.ray_diff + ((size_t)n * V + v) * 4) =
+                gpn_ray_diff(px, py, pz, a.qry_pos[0], a.qry_pos[1], a.qry_pos[2], sPos[v * 3 + 0],
+                             sPos[v * 3 + 1], sPos[v * 3 + 2]);
+        }
+      }
+      const unsigned long long zb = __ballot(zero_row);  // bit 16 g + j
+      // ---- phase 2: the group's views one after the other
+      for (int g2 = 0; g2 < 4 && vb + g2 < V; ++g2) {
+        const int v = vb + g2;
+        const unsigned zmask = (unsigned)(zb >> (16 * g2)) & 0xffffu;  // wave-uniform
+        f4 y[4];
+        if (zmask == 0xffffu) {  // every row of this (tile, view) is zero: no gather, no MLP
+#pragma unroll
+          for (int M = 0; M < 4; ++M) y[M] = c0[M];
+        } else {
+          const int e = 16 * g2 + j;
+          const int fx = tab.fx[e], fy = tab.fy[e];
+          const f4 w = (f4){tab.fw[0][e], tab.fw[1][e], tab.fw[2][e], tab.fw[3][e]};
+          const float* fm = a.feat + (size_t)v * fh_ * fw_ * 32 + 4 * g;
+          const int x0 = fx & 0xffff, x1 = (int)((unsigned)fx >> 16), y0 = (fy & 0xffff) * fw_, y1 = (int)((unsigned)fy >> 16) * fw_;
+          const int o00 = (y0 + x0) * 32, o01 = (y0 + x1) * 32, o10 = (y1 + x0) * 32, o11 = (y1 + x1) * 32;
+          f4 x[3];
+#pragma unroll
+          for (int T = 0; T < 2; ++T) {
+            const f4 tnw = ld4(fm + o00 + 16 * T), tne = ld4(fm + o01 + 16 * T);
+            const f4 tsw = ld4(fm + o10 + 16 * T), tse = ld4(fm + o11 + 16 * T);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[T][c] = gpn_bilerp4(tnw[c], tne[c], tsw[c], tse[c], w.x, w.y, w.z, w.w);
+          }
+          x[2] = f4_zero();
+          if (g == 0) {  // RGB: channels 32..34 of the gather order
+            const int rx = tab.rx[e], ry = tab.ry[e];
+            const f4 u = (f4){tab.rw[0][e], tab.rw[1][e], tab.rw[2][e], tab.rw[3][e]};
+            const float* im = a.rgb + (size_t)v * rh_ * rw_ * 3;
+            const int X0 = rx & 0xffff, X1 = (int)((unsigned)rx >> 16), Y0 = (ry & 0xffff) * rw_, Y1 = (int)((unsigned)ry >> 16) * rw_;
+            const int p00 = (Y0 + X0) * 3, p01 = (Y0 + X1) * 3, p10 = (Y1 + X0) * 3, p11 = (Y1 + X1) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+              x[2][c] = gpn_bilerp4(im[p00 + c], im[p01 + c], im[p10 + c], im[p11 + c], u.x, u.y, u.z, u.w);
+          }
+          mlp(x, y);
+        }
+        if ((wr >> v) & 1u) store_row(n, v, y);
+#pragma unroll
+        for (int M = 0; M < 4; ++M) qmax[M] = f4_max(qmax[M], y[M]);
+      }
+    }
+    if (valid) {
+#pragma unroll
+      for (int M = 0; M < 4; ++M) st4(q0 + (size_t)n * C64 + 16 * M + 4 * g, qmax[M]);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ visibility order
 // Counting sort of the points by their set of visible views (bit v = mask[n][v] != 0; hashed to 12
 // bits when V > 12).  The order inside a bin is arbitrary: every point is computed independently of
@@ -2053,6 +2266,54 @@ extern "C" int gpn_rgbfeat(const gpn_linear_t* fc0, const gpn_linear_t* fc2, con
   return GPN_OK;
 }
 
+static size_t proj_rgbfeat_lds(bool spl) {
+  return sizeof(float) * (wimg_floats(spl, 64, 3, RF_LD0) + wimg_floats(spl, 64, 4, LDW) + 128 +
+                          GPN_MAX_VIEWS * 15) + (PR_TPB / 64) * sizeof(PrTab);
+}
+
+extern "C" int gpn_project_rgbfeat(const gpn_project_args_t* a, const gpn_linear_t* fc0,
+                                   const gpn_linear_t* fc2, float* feat, float* q0, int precision,
+                                   gpn_stream_t stream) {
+  GPN_REQUIRE_PREC(precision, "gpn_project_rgbfeat");
+  GPN_REQUIRE(a, "gpn_project_rgbfeat: null args");
+  if (a->N == 0) return GPN_OK;  // empty batch
+  GPN_REQUIRE(fc0 && fc2 && feat && q0, "gpn_project_rgbfeat: null pointer");
+  GPN_REQUIRE(a->xyz && a->proj && a->src_pos && a->rgb && a->feat && a->mask && a->ray_diff,
+              "gpn_project_rgbfeat: xyz, proj, src_pos, rgb, feat, mask and ray_diff are required");
+  GPN_REQUIRE(!a->rgb_feat && !a->deep_out && !a->pix && !a->taps && !a->front,
+              "gpn_project_rgbfeat: rgb_feat / deep_out / pix / taps / front are outputs of gpn_project_gather only");
+  GPN_REQUIRE(a->N > 0 && a->V >= 1 && a->V <= GPN_MAX_VIEWS, "gpn_project_rgbfeat: need 1 <= V <= %d (got %d)",
+              GPN_MAX_VIEWS, a->V);
+  GPN_REQUIRE_INT_RANGE(a->N, 1, a->V, "gpn_project_rgbfeat");
+  GPN_REQUIRE(a->feat_c == 32, "gpn_project_rgbfeat: feature maps must have 32 channels (got %d)", a->feat_c);
+  GPN_REQUIRE(a->feat_h >= 1 && a->feat_w >= 1 && a->rgb_h >= 1 && a->rgb_w >= 1 && a->feat_w <= 32767 &&
+                  a->feat_h <= 32767 && a->rgb_w <= 32767 && a->rgb_h <= 32767 &&
+                  (long long)a->feat_h * a->feat_w * 32 < 2147483647LL &&
+                  (long long)a->rgb_h * a->rgb_w * 3 < 2147483647LL,
+              "gpn_project_rgbfeat: unsupported map size (features %dx%d, rgb %dx%d)", a->feat_h, a->feat_w,
+              a->rgb_h, a->rgb_w);
+  GPN_REQUIRE(a->img_h > 1.0f && a->img_w > 1.0f, "gpn_project_rgbfeat: bad image size");
+  GPN_REQUIRE(fc0->w, "gpn_project_rgbfeat: null weight");
+  REQ_LIN(*fc2, "gpn_project_rgbfeat.fc2");
+  GPN_REQUIRE(aligned16(feat) && aligned16(q0) && aligned16(a->feat) && aligned16(a->ray_diff),
+              "gpn_project_rgbfeat: feat, q0, the feature maps and ray_diff must be 16-byte aligned");
+  const bool spl = precision == GPN_PREC_BF16X3;
+  const size_t lds = proj_rgbfeat_lds(spl);
+  int rc = set_lds_limit(spl ? reinterpret_cast<const void*>(k_proj_rgbfeat<true>)
+                             : reinterpret_cast<const void*>(k_proj_rgbfeat<false>), lds);
+  if (rc) return rc;
+  const int grid = persistent_grid(((long long)a->N + (PR_TPB / 4) - 1) / (PR_TPB / 4), PR_BPC);
+  GpnStageTimer timer_(GPN_ST_PROJ_RGBFEAT, (hipStream_t)stream);
+  if (spl)
+    hipLaunchKernelGGL(k_proj_rgbfeat<true>, dim3(grid), dim3(PR_TPB), lds, (hipStream_t)stream, *a, *fc0, *fc2,
+                       feat, q0);
+  else
+    hipLaunchKernelGGL(k_proj_rgbfeat<false>, dim3(grid), dim3(PR_TPB), lds, (hipStream_t)stream, *a, *fc0, *fc2,
+                       feat, q0);
+  GPN_LAUNCH_CHECK("k_proj_rgbfeat");
+  return GPN_OK;
+}
+
 extern "C" size_t gpn_vis_order_scratch_bytes(void) { return 2 * VIS_BINS * sizeof(int); }
 
 extern "C" int gpn_vis_order(const float* mask, int N, int V, int32_t* perm, void* scratch,
@@ -2319,7 +2580,7 @@ extern "C" int gpn_heads(const gpn_gnt_weights_t* W, const float* q, const float
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct GntWs {
-  size_t emb, emb_ray, feat, q, hidden, stats, abar, weights, pre, perm, vis_scratch, total;
+  size_t emb, emb_ray, feat, q, hidden, stats, abar, weights, pre, perm, vis_scratch, rdiff, mask, total;
 };
 static GntWs gnt_ws_layout(int R, int S, int V, int depth) {
   const size_t N = (size_t)R * S, f = sizeof(float);
@@ -2336,6 +2597,8 @@ static GntWs gnt_ws_layout(int R, int S, int V, int depth) {
   w.pre = o, o += align_up((size_t)R * GPN_SEM * f);
   w.perm = o, o += align_up(2 * N * sizeof(int));  // points in slot order | their visibility bits
   w.vis_scratch = o, o += align_up(2 * VIS_BINS * sizeof(int));
+  w.rdiff = o, o += align_up(N * V * 4 * f);  // gpn_render_pass: ray_diff / mask of the fused projector
+  w.mask = o, o += align_up(N * V * f);
   w.total = o;
   return w;
 }
@@ -2345,13 +2608,15 @@ extern "C" size_t gpn_gnt_workspace_bytes(int R, int S, int V, int depth) {
   return gnt_ws_layout(R, S, V, depth).total;
 }
 
-extern "C" int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat, int rgb_feat_ld,
-                               const float* ray_diff, const float* mask, const float* pts,
-                               const float* ray_d, const float* z_vals, int R, int S, int V,
-                               gpn_sem_args_t* sem, float* out, float* depth, float* sem_feat,
-                               void* workspace, size_t workspace_bytes, gpn_stream_t stream) {
+// proj == nullptr: gpn_gnt_forward (rgb_feat / ray_diff / mask given).  proj != nullptr: gpn_render_pass --
+// the fused projector + rgbfeat kernel produces feat, q0, ray_diff and mask from the source maps.
+static int gnt_forward_impl(const gpn_gnt_weights_t* W, const gpn_project_args_t* proj, const float* rgb_feat,
+                            int rgb_feat_ld, const float* ray_diff, const float* mask, const float* pts,
+                            const float* ray_d, const float* z_vals, int R, int S, int V,
+                            gpn_sem_args_t* sem, float* out, float* depth, float* sem_feat,
+                            void* workspace, size_t workspace_bytes, gpn_stream_t stream) {
   if (R == 0) return GPN_OK;  // empty batch (pointers may be null)
-  GPN_REQUIRE(W && rgb_feat && ray_diff && mask && pts && ray_d && out && workspace,
+  GPN_REQUIRE(W && (proj || (rgb_feat && ray_diff && mask)) && pts && ray_d && out && workspace,
               "gpn_gnt_forward: null pointer");
   const int D = W->trans_depth;
   GPN_REQUIRE(D >= 1 && D <= GPN_MAX_DEPTH, "gpn_gnt_forward: trans_depth must be in [1,%d]",
@@ -2377,10 +2642,20 @@ extern "C" int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat
   float* pre = reinterpret_cast<float*>(ws + L.pre);
   int32_t* perm = reinterpret_cast<int32_t*>(ws + L.perm);
   int rc;
+  if (proj) {
+    gpn_project_args_t pa = *proj;
+    pa.xyz = pts, pa.N = (int)N;
+    if (!pa.ray_diff) pa.ray_diff = reinterpret_cast<float*>(ws + L.rdiff);
+    if (!pa.mask) pa.mask = reinterpret_cast<float*>(ws + L.mask);
+    GPN_REQUIRE(pa.V == V && pa.feat_c == W->in_feat_ch, "gpn_render_pass: proj.V / proj.feat_c do not match");
+    if ((rc = gpn_project_rgbfeat(&pa, &W->rgbfeat0, &W->rgbfeat2, feat, q, prec, stream))) return rc;
+    ray_diff = pa.ray_diff, mask = pa.mask;
+  }
   if ((rc = gpn_vis_order(mask, (int)N, V, perm, ws + L.vis_scratch, stream))) return rc;
   if ((rc = gpn_posenc(pts, ray_d, R, S, emb, emb_ray, stream))) return rc;
   // (mask given: the feature rows of masked pairs, which gpn_view_attn never uses, are not stored)
-  if ((rc = gpn_rgbfeat(&W->rgbfeat0, &W->rgbfeat2, rgb_feat, (int)N, V, 3 + W->in_feat_ch, rgb_feat_ld,
+  if (!proj &&
+      (rc = gpn_rgbfeat(&W->rgbfeat0, &W->rgbfeat2, rgb_feat, (int)N, V, 3 + W->in_feat_ch, rgb_feat_ld,
                         mask, feat, q, prec, stream)))
     return rc;
   for (int l = 0; l < D; ++l) {
@@ -2410,6 +2685,25 @@ extern "C" int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat
     if ((rc = gpn_sem_aggregate(sem, stream))) return rc;
   }
   return gpn_heads(W, q, wts, z_vals, sem ? pre : nullptr, R, S, out, depth, sem_feat, stream);
+}
+
+extern "C" int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat, int rgb_feat_ld,
+                               const float* ray_diff, const float* mask, const float* pts,
+                               const float* ray_d, const float* z_vals, int R, int S, int V,
+                               gpn_sem_args_t* sem, float* out, float* depth, float* sem_feat,
+                               void* workspace, size_t workspace_bytes, gpn_stream_t stream) {
+  return gnt_forward_impl(W, nullptr, rgb_feat, rgb_feat_ld, ray_diff, mask, pts, ray_d, z_vals, R, S, V, sem,
+                          out, depth, sem_feat, workspace, workspace_bytes, stream);
+}
+
+extern "C" int gpn_render_pass(const gpn_gnt_weights_t* W, const gpn_project_args_t* proj, const float* pts,
+                               const float* ray_d, const float* z_vals, int R, int S, gpn_sem_args_t* sem,
+                               float* out, float* depth, float* sem_feat, void* workspace,
+                               size_t workspace_bytes, gpn_stream_t stream) {
+  if (R == 0) return GPN_OK;
+  GPN_REQUIRE(proj, "gpn_render_pass: null projector arguments");
+  return gnt_forward_impl(W, proj, nullptr, 0, nullptr, nullptr, pts, ray_d, z_vals, R, S, proj->V, sem, out,
+                          depth, sem_feat, workspace, workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------ allocation-free forward

@@ -94,3 +94,22 @@ __device__ __forceinline__ float gpn_bilerp4(float vnw, float vne, float vsw, fl
   o = __builtin_fmaf(vse, wse, o);
   return o;
 }
+
+// compute_angle (reference projection.py:57-82) for one (point, view) pair: unit(o_q - x) - unit(o_v - x),
+// normalised (clamped at 1e-6), and the dot product of the two unit vectors.  Every operation rounded
+// separately, in the reference's order.
+__device__ __forceinline__ float4 gpn_ray_diff(float x, float y, float z, float qx, float qy, float qz,
+                                               float sx, float sy, float sz) {
+#pragma clang fp contract(off)
+  float ax = qx - x, ay = qy - y, az = qz - z;
+  const float na = sqrtf(ax * ax + ay * ay + az * az) + 1e-6f;
+  ax /= na, ay /= na, az /= na;
+  float bx = sx - x, by = sy - y, bz = sz - z;
+  const float nb = sqrtf(bx * bx + by * by + bz * bz) + 1e-6f;
+  bx /= nb, by /= nb, bz /= nb;
+  const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  float nd = sqrtf(dx * dx + dy * dy + dz * dz);
+  const float dot = ax * bx + ay * by + az * bz;
+  nd = nd < 1e-6f ? 1e-6f : nd;
+  return make_float4(dx / nd, dy / nd, dz / nd, dot);
+}

@@ -100,19 +100,10 @@ k_project_feat(gpn_project_args_t a, long long n_pairs) {
           a.pix[((size_t)v * a.N + n) * 2 + 0] = pp.px;
           a.pix[((size_t)v * a.N + n) * 2 + 1] = pp.py;
         }
-        if (a.ray_diff) {  // ray_diff (projection.py:65-82)
-          float ax = a.qry_pos[0] - x, ay = a.qry_pos[1] - y, az = a.qry_pos[2] - z;
-          const float na = sqrtf(ax * ax + ay * ay + az * az) + 1e-6f;
-          ax /= na, ay /= na, az /= na;
-          float bx = sPos[v * 3 + 0] - x, by = sPos[v * 3 + 1] - y, bz = sPos[v * 3 + 2] - z;
-          const float nb = sqrtf(bx * bx + by * by + bz * bz) + 1e-6f;
-          bx /= nb, by /= nb, bz /= nb;
-          const float dx = ax - bx, dy = ay - by, dz = az - bz;
-          float nd = sqrtf(dx * dx + dy * dy + dz * dz);
-          const float dot = ax * bx + ay * by + az * bz;
-          nd = nd < 1e-6f ? 1e-6f : nd;
-          *reinterpret_cast<float4*>(a.ray_diff + pair * 4) = make_float4(dx / nd, dy / nd, dz / nd, dot);
-        }
+        if (a.ray_diff)  // ray_diff (projection.py:65-82)
+          *reinterpret_cast<float4*>(a.ray_diff + pair * 4) =
+              gpn_ray_diff(x, y, z, a.qry_pos[0], a.qry_pos[1], a.qry_pos[2], sPos[v * 3 + 0], sPos[v * 3 + 1],
+                           sPos[v * 3 + 2]);
       }
     }
     if (!gather) continue;  // uniform across the block

@@ -157,6 +157,20 @@ class Projector:
         _lib.check(_lib.lib().gpn_project_gather(C.byref(a), _lib.stream()), "gpn_project_gather")
         return out
 
+    def fused_args(self, sv):
+        """gpn_project_args_t of the source views for gpn_render_pass (projector fused into the network's
+        first stage): maps and cameras only -- points, N and the outputs are filled in by the callee."""
+        if sv.feat is None:
+            raise ValueError("the fused path needs feature maps")
+        a = _lib.ProjectArgs()
+        a.proj, a.src_pos = _lib.ptr(sv.proj), _lib.ptr(sv.src_pos)
+        a.qry_pos = (C.c_float * 3)(*sv.qry_pos)
+        a.img_h, a.img_w, a.V = sv.img_h, sv.img_w, sv.V
+        a.rgb, a.rgb_h, a.rgb_w = _lib.ptr(sv.rgb), sv.rgb.shape[1], sv.rgb.shape[2]
+        a.feat = _lib.ptr(sv.feat)
+        a.feat_h, a.feat_w, a.feat_c = sv.feat.shape[1:]
+        return a
+
     # ------------------------------------------------------------------ reference API
     def compute_projections(self, xyz, train_cameras):
         """reference projection.py:31-55: pix [V,...,2], in-front mask [V,...] (bool)."""

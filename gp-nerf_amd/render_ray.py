@@ -111,15 +111,15 @@ def raw2outputs(raw, z_vals, mask, white_bkgd=False):
 
 
 def _gnt_pass(net, projector, sv, pts, z_vals, ray_d, ret_alpha, want_3d=True):
-    """One coarse/fine pass on the fused path: project+gather (35 ch), GNT, semantic aggregation
-    straight from the NHWC deep-semantic maps (no [R,S,V,512] tensor)."""
-    rgb_feat, ray_diff, mask = projector.compute_fused(pts, sv)
+    """One coarse/fine pass on the fused path (gpn_render_pass): the projector runs fused into the
+    network's first stage (no [R,S,V,35] tensor), the semantic aggregation samples the NHWC
+    deep-semantic maps itself (no [R,S,V,512] tensor)."""
     deep_map = None
     if sv.deep is not None:
         deep_map = dict(map=sv.deep, proj=sv.proj, img_h=sv.img_h, img_w=sv.img_w)
     out, depth, feats_out, feats_out_3d = net.run(
-        rgb_feat, ray_diff, mask, pts, ray_d, z_vals=z_vals if ret_alpha else None,
-        deep_map=deep_map, want_sem3d=want_3d)
+        None, None, None, pts, ray_d, z_vals=z_vals if ret_alpha else None,
+        deep_map=deep_map, want_sem3d=want_3d, proj=projector.fused_args(sv))
     if ret_alpha:
         rgb, weights = out[:, 0:3], out[:, 3:]
     else:

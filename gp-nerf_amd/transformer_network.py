@@ -184,22 +184,37 @@ class GNT(nn.Module):
 
     # ------------------------------------------------------------------ kernels
     def run(self, rgb_feat, ray_diff, mask, pts, ray_d, z_vals=None, deep_dense=None, deep_map=None,
-            want_sem3d=True):
+            want_sem3d=True, proj=None, return_mask=False):
         """Shared driver of `forward` (materialised deep_sem) and render_rays' fused path (deep maps).
 
         deep_map: dict(map=[V,Hs,Ws,512] NHWC, proj=[V,4,4], img_h, img_w) or None.
-        Returns out [R,3+S], depth [R] or None, sem_feat [R,512] or None, sem_feat_3d or None."""
-        rgb_feat = _lib.dev_f32(_lib.as_f32c(rgb_feat), "rgb_feat")
-        R, S, V = rgb_feat.shape[:3]
-        # 3+F channels (reference layout) or rows padded to 36 floats (Projector.compute_fused)
+        proj: a gpn_project_args_t of the source views (Projector.fused_args) -- the projector then runs
+        fused into the network's first stage (gpn_render_pass) and rgb_feat / ray_diff / mask are None.
+        Returns out [R,3+S], depth [R] or None, sem_feat [R,512] or None, sem_feat_3d or None
+        (+ mask [R,S,V] with return_mask, fused path only)."""
+        pts = _lib.dev_f32(_lib.as_f32c(pts), "pts")
+        if pts.dim() != 3 or pts.shape[2] != 3:
+            raise ValueError("pts must be [R,S,3]")
+        R, S = pts.shape[:2]
+        dev = pts.device
         in_ch = 3 + self.in_feat_ch
-        ld = rgb_feat.shape[3]
-        if ld != in_ch and not (ld == 36 and in_ch <= 36):
-            raise ValueError("rgb_feat must have %d channels" % in_ch)
-        dev = rgb_feat.device
-        ray_diff = _lib.dev_f32(_lib.as_f32c(ray_diff), "ray_diff", (R, S, V, 4))
-        mask = _lib.dev_f32(_lib.as_f32c(mask), "mask").reshape(R, S, V)
-        pts = _lib.dev_f32(_lib.as_f32c(pts), "pts", (R, S, 3))
+        mask_out = None
+        if proj is None:
+            rgb_feat = _lib.dev_f32(_lib.as_f32c(rgb_feat), "rgb_feat")
+            if tuple(rgb_feat.shape[:2]) != (R, S):
+                raise ValueError("rgb_feat must be [R,S,V,.]")
+            V = rgb_feat.shape[2]
+            # 3+F channels (reference layout) or rows padded to 36 floats (Projector.compute_fused)
+            ld = rgb_feat.shape[3]
+            if ld != in_ch and not (ld == 36 and in_ch <= 36):
+                raise ValueError("rgb_feat must have %d channels" % in_ch)
+            ray_diff = _lib.dev_f32(_lib.as_f32c(ray_diff), "ray_diff", (R, S, V, 4))
+            mask = _lib.dev_f32(_lib.as_f32c(mask), "mask").reshape(R, S, V)
+        else:
+            V = proj.V
+            if return_mask:
+                mask_out = torch.empty((R, S, V), device=dev)
+                proj.mask = _lib.ptr(mask_out)
         ray_d = _lib.dev_f32(_lib.as_f32c(ray_d), "ray_d", (R, 3))
         if S < 1 or S > _lib.MAX_SAMPLES:
             raise ValueError("samples per ray must be in [1,%d] (got %d)" % (_lib.MAX_SAMPLES, S))
@@ -228,11 +243,20 @@ class GNT(nn.Module):
                 sem.deep_map, sem.deep_h, sem.deep_w = _lib.ptr(m), m.shape[1], m.shape[2]
                 sem.xyz, sem.proj = _lib.ptr(pts), _lib.ptr(deep_map["proj"])
                 sem.img_h, sem.img_w = deep_map["img_h"], deep_map["img_w"]
-        _lib.check(_lib.lib().gpn_gnt_forward(
-            C.byref(W), _lib.ptr(rgb_feat), ld, _lib.ptr(ray_diff), _lib.ptr(mask), _lib.ptr(pts),
-            _lib.ptr(ray_d), _lib.ptr(z_vals), R, S, V, C.byref(sem) if sem is not None else None,
-            _lib.ptr(out), _lib.ptr(depth), _lib.ptr(sem_feat), _lib.ptr(ws), need, _lib.stream()),
-            "gpn_gnt_forward")
+        semp = C.byref(sem) if sem is not None else None
+        if proj is None:
+            _lib.check(_lib.lib().gpn_gnt_forward(
+                C.byref(W), _lib.ptr(rgb_feat), ld, _lib.ptr(ray_diff), _lib.ptr(mask), _lib.ptr(pts),
+                _lib.ptr(ray_d), _lib.ptr(z_vals), R, S, V, semp,
+                _lib.ptr(out), _lib.ptr(depth), _lib.ptr(sem_feat), _lib.ptr(ws), need, _lib.stream()),
+                "gpn_gnt_forward")
+        else:
+            _lib.check(_lib.lib().gpn_render_pass(
+                C.byref(W), C.byref(proj), _lib.ptr(pts), _lib.ptr(ray_d), _lib.ptr(z_vals), R, S, semp,
+                _lib.ptr(out), _lib.ptr(depth), _lib.ptr(sem_feat), _lib.ptr(ws), need, _lib.stream()),
+                "gpn_render_pass")
+        if return_mask:
+            return out, depth, sem_feat, sem3d, mask_out
         return out, depth, sem_feat, sem3d
 
     @torch.no_grad()

@@ -149,6 +149,19 @@ typedef struct {
   const float* b; /* [out] or NULL */
 } gpn_linear_t;
 
+/* Projector.compute (without the deep-semantic gather) fused with rgbfeat_fc + max over views, reference
+ * gpnerf/projection.py:31-139 + transformer_network.py:309-311: the fast path of render_rays.  Same
+ * arguments as gpn_project_gather (a->mask and a->ray_diff required; rgb_feat / deep_out / pix / taps /
+ * front must be NULL) and the outputs of gpn_rgbfeat: feat [N,V,C] in the layout of `precision`, q0 [N,C].
+ * The [N,V,3+F] tensor is never formed; pairs whose gathered row is exactly zero (every bilinear tap
+ * outside both maps) take the constant row fc2(relu(fc0.bias)) without a gather or an MLP evaluation.
+ * mask is written for every pair; ray_diff and the feature row only for the pairs gpn_view_attn reads
+ * (visible pairs, and every view of a point without any visible view).  mask bit-exact with
+ * gpn_project_gather; feat / q0 agree with gpn_rgbfeat(gpn_project_gather(...)) to fp32 rounding (the
+ * input channels are summed features-first).  Map sides <= 32767. */
+int gpn_project_rgbfeat(const gpn_project_args_t* a, const gpn_linear_t* fc0, const gpn_linear_t* fc2,
+                        float* feat, float* q0, int precision, gpn_stream_t stream);
+
 typedef struct {                 /* Transformer2D + Attention2D, transformer_network.py:55-122 */
   const float *attn_norm_w, *attn_norm_b, *ff_norm_w, *ff_norm_b;
   gpn_linear_t ff1, ff2;         /* [4C,C], [C,4C] */
@@ -307,6 +320,16 @@ int gpn_gnt_forward(const gpn_gnt_weights_t* W, const float* rgb_feat, int rgb_f
                     int R, int S, int V, gpn_sem_args_t* sem, float* out, float* depth,
                     float* sem_feat, void* workspace, size_t workspace_bytes, gpn_stream_t stream);
 
+/* One pass of render_rays' inner block, reference gpnerf/render_ray.py:239-256 (coarse) / :275-296
+ * (fine): Projector.compute + GNT.forward + the depth expectation, with the projector fused into the
+ * network's first stage (gpn_project_rgbfeat).  proj: the source views as for gpn_project_gather (its xyz /
+ * N are taken from pts / R*S; ray_diff / mask may be NULL: they then live in the workspace; rgb_feat,
+ * deep_out, pix, taps, front must be NULL).  Everything else as gpn_gnt_forward, same workspace size. */
+int gpn_render_pass(const gpn_gnt_weights_t* W, const gpn_project_args_t* proj, const float* pts,
+                    const float* ray_d, const float* z_vals, int R, int S, gpn_sem_args_t* sem,
+                    float* out, float* depth, float* sem_feat, void* workspace, size_t workspace_bytes,
+                    gpn_stream_t stream);
+
 /* gpn_gnt_forward without a caller workspace and without any allocation.  It has NO counterpart in
  * the reference: it exists for callers that cannot allocate device memory around the call -- code
  * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  The workspace is a
@@ -337,7 +360,7 @@ int gpn_gnt_forward_static(const gpn_gnt_weights_t* W, const float* rgb_feat, in
 enum {
   GPN_ST_SAMPLE = 0, GPN_ST_PROJECT, GPN_ST_PROJECT_DEEP, GPN_ST_POSENC, GPN_ST_RGBFEAT,
   GPN_ST_VIEW_ATTN, GPN_ST_FF, GPN_ST_QPOS, GPN_ST_RAY_ATTN, GPN_ST_SEM, GPN_ST_HEADS,
-  GPN_ST_VIS_ORDER, GPN_NSTAGES
+  GPN_ST_VIS_ORDER, GPN_ST_PROJ_RGBFEAT, GPN_NSTAGES
 };
 int gpn_timing_begin(unsigned stage_mask, int max_records);
 int gpn_timing_end(double* ms_per_stage, long long* launches_per_stage);

@@ -451,6 +451,74 @@ def test_gnt_stages(dev, net, prec, S):
     assert not bad, "stage errors above %g: %s (all: %s)" % (STAGE_TOL[prec], bad, errs)
 
 
+@pytest.mark.parametrize("case", ["g1", "rig10"])
+def test_fused_projector_rgbfeat(dev, net, prec, case):
+    """gpn_project_rgbfeat (the projector fused into the network's first stage) against the two-kernel
+    path gpn_project_gather -> gpn_rgbfeat on the same points: mask bit-exact for every pair; ray_diff
+    bit-exact and the feature row within the stage tolerance wherever gpn_view_attn reads them (visible
+    pairs; every view of a point without a visible view), nothing written elsewhere; q0 (max over ALL
+    views, zero rows included through the constant row) within the stage tolerance.  'g1': the projector
+    golden case (points behind cameras, on borders, outside every frustum); 'rig10': 10 views, 3000 points
+    (several tiles per wave, ragged last tile)."""
+    from gp_nerf_amd import _lib, synth
+    from gp_nerf_amd.projection import Projector
+    L, st, pc = _lib.lib(), _lib.stream(), _lib.precision_code(prec)
+    P = Projector(dev)
+    if case == "g1":
+        c = cases.g1_projector()
+        cd = to(dev, c)
+        pts, cam, rgbs, cams, fm = cd["pts"], cd["camera"], cd["src_rgbs"], cd["src_cameras"], cd["featmaps"]
+    else:
+        K = synth.scaled_intrinsics(synth.SCANNET_K, 0.4, 0.4)
+        sc = synth.Scene(96, 128, 10, K, (0.1, 6.0), seed=21)
+        rb = to(dev, sc.ray_batch(start=3000, count=125))
+        z = 1.0 / torch.linspace(1.0 / 0.1, 1.0 / 6.0, 24, device=dev)
+        pts = (rb["ray_o"][:, None] + z[None, :, None] * rb["ray_d"][:, None]).contiguous()
+        cam, rgbs, cams, fm = rb["camera"], rb["src_rgbs"], rb["src_cameras"], sc.featmaps.to(dev)
+    sv = P.prepare(cam, rgbs, cams, fm, None)
+    rgb_feat, rd_ref, mask_ref = P.compute_fused(pts, sv)
+    R, S, V = rgb_feat.shape[:3]
+    N = R * S
+    W = net._weights()
+    feat_ref, q0_ref = torch.empty(N, V, 64, device=dev), torch.empty(N, 64, device=dev)
+    _lib.check(L.gpn_rgbfeat(C.byref(W.rgbfeat0), C.byref(W.rgbfeat2), _lib.ptr(rgb_feat), N, V, 35, 36,
+                             None, _lib.ptr(feat_ref), _lib.ptr(q0_ref), pc, st), "rgbfeat")
+    a = P.fused_args(sv)
+    ptsc = pts.reshape(N, 3).contiguous()
+    a.xyz, a.N = _lib.ptr(ptsc), N
+    mask = torch.full((N, V), float("nan"), device=dev)
+    rd = torch.full((N, V, 4), float("nan"), device=dev)
+    feat = torch.full((N, V, 64), float("nan"), device=dev)
+    q0 = torch.empty(N, 64, device=dev)
+    a.mask, a.ray_diff = _lib.ptr(mask), _lib.ptr(rd)
+    _lib.check(L.gpn_project_rgbfeat(C.byref(a), C.byref(W.rgbfeat0), C.byref(W.rgbfeat2), _lib.ptr(feat),
+                                     _lib.ptr(q0), pc, st), "project_rgbfeat")
+    torch.cuda.synchronize()
+    mref = mask_ref.reshape(N, V)
+    assert torch.equal(mask, mref), "mask differs from gpn_project_gather"
+    vis = mref != 0
+    live = vis | ~vis.any(dim=1, keepdim=True)
+    assert 0.05 < float(vis.float().mean()) < 0.95 and bool((~vis.any(dim=1)).any()), "case lost its coverage"
+    assert torch.equal(rd[live].view(torch.int32), rd_ref.reshape(N, V, 4)[live].view(torch.int32))
+    assert bool(torch.isnan(rd[~live]).all()) and bool(torch.isnan(feat[~live]).all()), \
+        "a pair gpn_view_attn never reads was written"
+    errs = {"feat": rel(dec_feat(feat[live], prec), dec_feat(feat_ref[live], prec)), "q0": rel(q0, q0_ref)}
+    print("fused projector+rgbfeat [%s, %s]: %s, visible %.2f" % (case, prec, errs, float(vis.float().mean())))
+    assert max(errs.values()) < STAGE_TOL[prec], errs
+    # zero rows: a pair with every tap outside both maps has the constant feature row (all-masked points store it)
+    zero_in = (rgb_feat.reshape(N, V, 36) == 0).all(dim=-1)
+    sel = zero_in & live
+    if bool(sel.any()):
+        rows = dec_feat(feat[sel], prec)
+        assert float((rows - rows[0]).abs().max()) == 0.0, "zero-input rows are not one constant row"
+    # empty batch and refused arguments
+    a.N = 0
+    assert L.gpn_project_rgbfeat(C.byref(a), C.byref(W.rgbfeat0), C.byref(W.rgbfeat2), None, None, pc, st) == 0
+    a.N, a.mask = N, None
+    assert L.gpn_project_rgbfeat(C.byref(a), C.byref(W.rgbfeat0), C.byref(W.rgbfeat2), _lib.ptr(feat),
+                                 _lib.ptr(q0), pc, st) == -1
+
+
 @pytest.mark.parametrize("scale", [1.0, 40.0, 400.0])
 def test_posenc_argument_ranges(dev, scale):
     """gpn_posenc's sin / cos: Cody-Waite reduction + polynomial kernels for |arg| <= 1e5, libm's

@@ -66,7 +66,7 @@ class ProjectArgs(C.Structure):
                 ("deep", C.c_void_p), ("deep_h", C.c_int), ("deep_w", C.c_int), ("deep_c", C.c_int),
                 ("rgb_feat", C.c_void_p), ("deep_out", C.c_void_p), ("ray_diff", C.c_void_p),
                 ("mask", C.c_void_p), ("pix", C.c_void_p), ("taps", C.c_void_p),
-                ("front", C.c_void_p), ("rgb_feat_ld", C.c_int)]
+                ("front", C.c_void_p), ("rgb_feat_ld", C.c_int), ("samples_per_ray", C.c_int)]
 
 
 class SemArgs(C.Structure):

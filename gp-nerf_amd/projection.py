@@ -133,6 +133,7 @@ class Projector:
         a.xyz, a.proj, a.src_pos = _lib.ptr(pts), _lib.ptr(sv.proj), _lib.ptr(sv.src_pos)
         a.qry_pos = (C.c_float * 3)(*sv.qry_pos)
         a.img_h, a.img_w, a.N, a.V = sv.img_h, sv.img_w, N, V
+        a.samples_per_ray = xyz.shape[-2] if xyz.dim() == 3 else 0  # scheduling hint of the deep gather
         a.rgb, a.rgb_h, a.rgb_w = _lib.ptr(sv.rgb), sv.rgb.shape[1], sv.rgb.shape[2]
         out = {}
         if want_feat:

@@ -136,6 +136,10 @@ typedef struct {
   int rgb_feat_ld;       /* floats between consecutive rgb_feat rows; 0 = 3+F (the reference's dense
                             layout).  36 gives 16-byte aligned rows (pad written as zeros): what
                             gpn_rgbfeat reads fastest; used by the fused path only */
+  int samples_per_ray;   /* S when xyz is [R,S,3] (N = R*S), else 0.  Scheduling hint only (results do
+                            not depend on it): the deep-semantic gather then walks neighbouring RAYS at
+                            one sample index and view back to back -- their bilinear taps share texels,
+                            which turns most 2 KB tap reads into cache hits */
 } gpn_project_args_t;
 
 /* Projector.compute = compute_projections + inbound + normalize + 3x grid_sample + compute_angle,

@@ -3,11 +3,11 @@
 A=$1; B=$2; steps=${3:-60}
 for rep in 1 2; do
   for lib in $A $B; do
-    GPN_LIB=$PWD/$lib timeout -k 10 200 python bench.py --cpu-rays 0 --only-timed --steps $steps --warmup 5 > /tmp/ab.log 2>&1 || { tail -5 /tmp/ab.log; exit 1; }
+    GPN_LIB=$PWD/$lib timeout -k 10 200 python bench.py --only-timed --precision ${PREC:-bf16x3} --steps $steps --warmup 5 > /tmp/ab.log 2>&1 || { tail -5 /tmp/ab.log; exit 1; }
     python - $lib <<'PY'
 import json,sys
 l=[x for x in open("/tmp/ab.log") if x.startswith("{")][-1]; d=json.loads(l)
-print("%-32s rays/s %.0f  ms/step %.3f  %s" % (sys.argv[1], d["value"], d["ms_per_step"], {k: d["stage_ms_one_step"][k] for k in ("project","rgbfeat","view_attn","ff","ray_attn","sem")}), flush=True)
+print("%-32s rays/s %.0f  ms/step %.3f  %s" % (sys.argv[1], d["value"], d["ms_per_step"], {k: v for k, v in d["stage_ms_one_step"].items() if v > 0.2}), flush=True)
 PY
   done
 done

@@ -55,7 +55,7 @@ HBM_PEAK_GBPS = 8000.0
 # what a bare copy kernel reaches on this GPU for k_view_attn's access shape (random 256-byte rows,
 # read + written; tools/micro/reqbench.hip, profiles/r01_reqbench.txt); sequential read-only: 6250
 RANDOM_ROW_RW_CEILING_GBPS = 4700.0
-TRAFFIC_FILE = "profiles/r02_pmc_traffic.json"
+TRAFFIC_FILE = "profiles/r02_pmc_traffic.json"  # tools/profile_round.sh r02 + tools/profile_collect.py r02
 
 RIGS = {
     # 15 cm / 5 cm offsets, 2 degrees of yaw per view, depth 0.1-10 m (mask mean ~0.41)
@@ -90,9 +90,9 @@ FF_FLOPS_PER_POINT = 2 * 2 * 64 * 256  # fc1 + fc2 of one FeedForward (SURVEY 8(
 # MFMA flops k_view_attn executes (MAC = 2; every bf16x3 product counts its three MFMAs).
 # bf16x3 (folded weights): per computed pair (Wv Wk) 8192 + pos_fc[2] 1024 + (A0 Wk | A0 P2) 1152 +
 # attn_fc[2] 1024 = 11392, x3; + fp32 pos_fc[0] 64.  Per point q_fc + out_fc + A0 q = 17408, x3.
-# fp32: the reference order, k 8192 + v 8192 + pos 64 + 1024 + attn 1024 + 1024 per pair, 16384 per point.
-VIEW_EXEC_FLOPS_PER_PAIR = {"bf16x3": 3 * 11392 + 64, "fp32": 19520}
-VIEW_EXEC_FLOPS_PER_POINT = {"bf16x3": 3 * 17408, "fp32": 16384}
+# fp32 (same folded products, one fp32 MFMA flop per algorithmic flop): 11392 + 64 per pair, 17408 per point.
+VIEW_EXEC_FLOPS_PER_PAIR = {"bf16x3": 3 * 11392 + 64, "fp32": 11392 + 64}
+VIEW_EXEC_FLOPS_PER_POINT = {"bf16x3": 3 * 17408, "fp32": 17408}
 
 
 def mfma_peak(precision):
@@ -104,7 +104,7 @@ def mfma_peak(precision):
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 as the
     gfx950 correction + WRITE_SIZE, separate runs of this same command).  None if the file is missing."""
-    for name in (TRAFFIC_FILE, "profiles/r01_pmc_traffic.json"):
+    for name in (TRAFFIC_FILE, "profiles/r02a_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, name)) as f:
                 return json.load(f)[kernel]["hbm_bytes_per_launch"], name

@@ -82,7 +82,19 @@ __device__ unsigned long long g_ffc[4][32];
 extern "C" int gpn_debug_ffc(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ffc), sizeof(g_ffc)) == hipSuccess ? 0 : 1;
 }
+// k_ray_attn: cycles a wave of workgroup 3 spends in each phase, summed over its iterations
+// [wave][0 = projections, 1 = barrier A, 2 = attention + out_fc + stores, 3 = barrier B, 4 = abar reduction, 5 = iterations]
+__device__ unsigned long long g_ra_phase[16][8];
+#define RA_T0() unsigned long long ra_t_ = __builtin_readcyclecounter(); unsigned long long ra_acc_[6] = {0, 0, 0, 0, 0, 0}
+#define RA_MARK(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); ra_acc_[k] += n_ - ra_t_; ra_t_ = n_; } while (0)
+#define RA_END() do { if (blockIdx.x == 3 && lane == 0 && wave < 16) { for (int k_ = 0; k_ < 6; ++k_) g_ra_phase[wave][k_] = ra_acc_[k_]; } } while (0)
+extern "C" int gpn_debug_ra_phase(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ra_phase), sizeof(g_ra_phase)) == hipSuccess ? 0 : 1;
+}
 #else
+#define RA_T0() do { } while (0)
+#define RA_MARK(k) do { } while (0)
+#define RA_END() do { } while (0)
 #define FFC(k) do { } while (0)
 #define STAMP(i) do { } while (0)
 #define STAMP_MIN() do { } while (0)
@@ -1646,7 +1658,9 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
     vo.store(bO, tid), vg.store(gam, tid), vb.store(bet, tid);
   }
   __syncthreads();
+  RA_T0();
   for (int grp = blockIdx.x; grp * RPW < R; grp += gridDim.x) {
+    RA_MARK(4);
     const int ray = grp * RPW + slot;
     const bool valid = ray < R;
     f4 x[4], xn[4], qT[4];
@@ -1695,7 +1709,9 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
           for (int r = 0; r < 4; ++r) Vt_s[(16 * M + 4 * g + r) * LDV + 16 * t + j] = vT[M][r];
       }
     }
+    RA_MARK(0);
     __syncthreads();
+    RA_MARK(1);
 
     // scores / sqrt(16): scale q once (exact, a power of two) instead of every score; in split mode
     // log2(e) rides along so that the softmax is a bare v_exp_f32 (2^x)
@@ -1853,7 +1869,12 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
           }
       }
     }
+    RA_MARK(2);
     __syncthreads();
+    RA_MARK(3);
+#ifdef GPN_STAMP
+    ra_acc_[5] += 1;
+#endif
     if (abar != nullptr) {
       for (int idx = tid; idx < RPW * 4 * SP; idx += NTHR) {
         const int sl = idx / (4 * SP), rem = idx - sl * 4 * SP;
@@ -1868,6 +1889,8 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
     // no third barrier: the next iteration writes Ks / Vt only (every wave is past the attention
     // phase here) and its own barrier separates these reads of `part` from the next writes to it
   }
+  RA_MARK(4);
+  RA_END();
 }
 
 // ------------------------------------------------------------------------------------ semantic aggregation

@@ -1713,10 +1713,10 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
     __syncthreads();
     RA_MARK(1);
 
-    // scores / sqrt(16): scale q once (exact, a power of two) instead of every score; in split mode
-    // log2(e) rides along so that the softmax is a bare v_exp_f32 (2^x)
+    // scores / sqrt(16): scale q once instead of every score; log2(e) rides along so that the softmax is a
+    // bare v_exp_f32 (2^x) in both modes
     {
-      const float qscale = SPL ? 0.25f * 1.44269504088896341f : 0.25f;
+      const float qscale = 0.25f * 1.44269504088896341f;
 #pragma unroll
       for (int M = 0; M < 4; ++M) qT[M] = qT[M] * f4_splat(qscale);
     }
@@ -1772,14 +1772,14 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
         for (int kt = 0; kt < NT; ++kt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            sT[kt][r] = SPL ? __builtin_amdgcn_exp2f(sT[kt][r] - mx) : __expf(sT[kt][r] - mx);
+            sT[kt][r] = __builtin_amdgcn_exp2f(sT[kt][r] - mx);
           sum += (sT[kt].x + sT[kt].y) + (sT[kt].z + sT[kt].w);
         }
         return sum_over_g(sum);
       };
       scores();
       float tot;
-      if constexpr (SPL) {
+      {
         // Softmax is shift invariant and the scores of LayerNorm'ed rows are small: take the bare
         // exponentials (no running maximum: 16 NT compare / subtract pairs and two cross-lane maxima
         // fewer per head) and fall back to the shifted form when a denominator leaves the safe range.
@@ -1796,8 +1796,6 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
           scores();
           tot = softmax_stable();
         }
-      } else {
-        tot = softmax_stable();
       }
       const float inv = __builtin_amdgcn_rcpf(tot);
 #pragma unroll

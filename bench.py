@@ -32,7 +32,8 @@ Prints ONE JSON line (rank 0):
   legs          the other 8(d) legs on the same scene: single_pass_64 (N_samples=64, N_importance=0: the
                 literal "4096 rays x 64 samples x 10 views"), dense_visibility (5 cm / no-yaw rig, near
                 plane 1 m: ~96 % of the (sample, view) pairs visible instead of ~41 %), projector_standalone
-                (Projector.compute with the 512-channel gather materialised, B_proj of SURVEY 8(d)).
+                (Projector.compute with the 512-channel gather materialised, B_proj of SURVEY 8(d)),
+                stress_shape (BASELINE configs[4] on one GPU: 16 views, 1296x968 images, 96 + 32 samples).
   cpu_baseline  the CPU oracle (a port of the reference path) on a bounded ray sample.
 """
 import argparse
@@ -62,7 +63,10 @@ RIGS = {
     "sparse": dict(rig=dict(), depth=(0.1, 10.0)),
     # the survey's tight rig: 5 cm spacing, no rotation; near plane at 1 m (mask mean ~0.96)
     "dense": dict(rig=dict(dx=0.05, dy=0.0, yaw_deg=0.0), depth=(1.0, 6.0)),
+    # BASELINE.json configs[4] (stress shape: 16 views, 1296x968 ScanNet-sized images, 128 samples)
+    "stress": dict(rig=dict(dx=0.06, dy=0.02, yaw_deg=-1.5), depth=(0.1, 6.0)),
 }
+STRESS = dict(views=16, hw=(968, 1296), n_samples=96, n_importance=32)
 
 
 # ---------------------------------------------------------------------------------------- flop / byte models
@@ -114,24 +118,24 @@ def pmc_traffic(kernel):
 
 
 # ---------------------------------------------------------------------------------------- scene
-def build(dev, seed=1234, rig="sparse"):
+def build(dev, seed=1234, rig="sparse", views=VIEWS, hw=(480, 640), K=None):
     from gp_nerf_amd import synth
     from gp_nerf_amd.projection import Projector
     from gp_nerf_amd.transformer_network import GNT
     import numpy as np
 
-    H, W = 480, 640
-    K = synth.REPLICA_K
+    H, W = hw
+    K = synth.REPLICA_K if K is None else K
     cfg = RIGS[rig]
     g = torch.Generator(device=dev).manual_seed(seed)
     scene = types.SimpleNamespace()
-    scene.H, scene.W, scene.rig = H, W, rig
+    scene.H, scene.W, scene.rig, scene.views = H, W, rig, views
     scene.camera = torch.from_numpy(synth.make_camera(H, W, K, np.eye(4)))[None].to(dev)
-    scene.src_cameras = torch.from_numpy(synth.source_rig(VIEWS, H, W, K, **cfg["rig"]))[None].to(dev)
+    scene.src_cameras = torch.from_numpy(synth.source_rig(views, H, W, K, **cfg["rig"]))[None].to(dev)
     scene.depth_range = torch.tensor([list(cfg["depth"])], device=dev)
-    scene.src_rgbs = torch.rand((1, VIEWS, H, W, 3), device=dev, generator=g)
-    scene.featmaps = torch.randn((VIEWS, 32, H // 4, W // 4), device=dev, generator=g)
-    scene.deep = torch.randn((VIEWS, 512, H // 2, W // 2), device=dev, generator=g)
+    scene.src_rgbs = torch.rand((1, views, H, W, 3), device=dev, generator=g)
+    scene.featmaps = torch.randn((views, 32, H // 4, W // 4), device=dev, generator=g)
+    scene.deep = torch.randn((views, 512, H // 2, W // 2), device=dev, generator=g)
     scene.rays_o, scene.rays_d = synth.rays_single_image(H, W, K, np.eye(4), 1)
     args = types.SimpleNamespace(netwidth=64, trans_depth=8, save_feature=False,
                                  semantic_model="fpn", num_classes=20)
@@ -139,6 +143,14 @@ def build(dev, seed=1234, rig="sparse"):
     net.load_state_dict(synth.gnt_state_dict())
     net = net.to(dev).eval()
     return scene, net, Projector(dev)
+
+
+def build_stress(dev):
+    """BASELINE.json configs[4] scene: 16 views of 1296x968 (ScanNet-sized) images."""
+    from gp_nerf_amd import synth
+    H, W = STRESS["hw"]
+    return build(dev, rig="stress", views=STRESS["views"], hw=(H, W),
+                 K=synth.scaled_intrinsics(synth.SCANNET_K, W / 320.0, H / 240.0))
 
 
 def rerig(scene, rig, dev):
@@ -220,7 +232,7 @@ def main():
     ap.add_argument("--only-timed", action="store_true",
                     help="skip the other arithmetic mode, the extra legs, the full-image run and the CPU baseline "
                          "(tools/profile_round.sh: the profiled kernels are then the timed workload only)")
-    ap.add_argument("--leg", default=None, choices=("single_pass_64", "dense_visibility", "projector_standalone"),
+    ap.add_argument("--leg", default=None, choices=("single_pass_64", "dense_visibility", "projector_standalone", "stress_shape"),
                     help="run ONLY this leg as the timed workload (profiling aid; prints the leg's block)")
     a = ap.parse_args()
     if a.only_timed:
@@ -418,7 +430,7 @@ def main():
     if rank == 0 and world == 1 and not a.only_timed:
         legs = {name: run_leg(name, a, dev, scene, rb, net, model, projector, make_step, measure,
                               stage_breakdown, world, rank)
-                for name in ("single_pass_64", "dense_visibility", "projector_standalone")}
+                for name in ("single_pass_64", "dense_visibility", "projector_standalone", "stress_shape")}
         net.precision = a.precision
 
     # secondary metric: seconds per full image through render_single_image, results
@@ -557,6 +569,43 @@ def run_leg(name, a, dev, scene, rb, net, model, projector, make_step, measure, 
                                                 "run)" % tsrc) if tsrc else None,
                              "k_project_deep_alone_GBps": (deep_bytes + VIEWS * 4 * 512 * (H // 2) * (W // 2)) /
                                                           (k_ms["project_deep"] * 1e-3) / 1e9}}
+    if name == "stress_shape":
+        # BASELINE.json configs[4] on ONE GPU: 16 source views, 1296x968 images (maps 324x242 / 648x484),
+        # 96 coarse + 32 importance samples (a 96- and a 128-sample pass), one 4096-ray chunk per step
+        from gp_nerf_amd.render_ray import render_rays
+        V, (H, W) = STRESS["views"], STRESS["hw"]
+        ns, ni = STRESS["n_samples"], STRESS["n_importance"]
+        sc, _, proj = build_stress(dev)
+        rbs = ray_chunk(sc, 0, 1, dev)
+
+        def step(collective=False):
+            return render_rays(rbs, model, sc.featmaps, sc.deep, proj, N_samples=ns, inv_uniform=True,
+                               N_importance=ni, det=True, ret_alpha=True, single_net=True)
+        out = {"workload": "BASELINE configs[4] on one GPU: two-pass render_rays, %d views, %dx%d images, %d + %d "
+                           "samples (%d- and %d-sample passes), chunk %d rays"
+                           % (V, W, H, ns, ni, ns, ns + ni, CHUNK)}
+        f_ref = f_ref_per_ray(V, [ns, ns + ni]) * CHUNK
+        for mode in ("fp32", "bf16x3"):
+            net.precision = mode
+            for _ in range(2):
+                r = step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                r = step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            peak, note = mfma_peak(mode)
+            fin = all(bool(torch.isfinite(r[lvl][k]).all()) for lvl in ("outputs_coarse", "outputs_fine")
+                      for k in ("rgb", "depth", "weights", "feats_out"))
+            out[mode] = {"precision": mode, "value": CHUNK / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt,
+                         "finite": fin,
+                         "path_mfma": {"F_ref_TFLOP_per_step": f_ref / 1e12, "achieved_TFLOPs": f_ref / dt / 1e12,
+                                       "peak_TFLOPs": peak, "frac": f_ref / dt / 1e12 / peak, "peak_note": note},
+                         "stage_ms_one_step": stage_breakdown(step, mode)}
+        del sc, proj, rbs, r
+        torch.cuda.empty_cache()
+        return out
     raise ValueError(name)
 
 

@@ -1984,9 +1984,11 @@ k_sem(gpn_sem_args_t a) {
   struct TapTab {
     unsigned o00, o01, o10, o11;
     float wnw, wne, wsw, wse;
+    unsigned hit;  // views with a tap inside their map (wave-uniform; the others sample exact zeros)
   };
   auto tap_table = [&](size_t n_) {
-    TapTab t_ = {0, 0, 0, 0, 0.f, 0.f, 0.f, 0.f};
+    TapTab t_ = {0, 0, 0, 0, 0.f, 0.f, 0.f, 0.f, 0xffffffffu};
+    bool hit_ = false;
     if (!dense && lane < V) {
       const float px = a.xyz[n_ * 3 + 0], py = a.xyz[n_ * 3 + 1], pz = a.xyz[n_ * 3 + 2];
       const GpnPix pp = gpn_project(sP + lane * 12, px, py, pz);
@@ -1997,7 +1999,9 @@ k_sem(gpn_sem_args_t a) {
       t_.o10 = (unsigned)y1 * urs + (unsigned)x0 * GPN_SEM, t_.o11 = (unsigned)y1 * urs + (unsigned)x1 * GPN_SEM;
       t_.wnw = (t.vy0 && t.vx0) ? t.nw : 0.0f, t_.wne = (t.vy0 && t.vx1) ? t.ne : 0.0f;
       t_.wsw = (t.vy1 && t.vx0) ? t.sw : 0.0f, t_.wse = (t.vy1 && t.vx1) ? t.se : 0.0f;
+      hit_ = (t.vy0 || t.vy1) && (t.vx0 || t.vx1);
     }
+    if (!dense) t_.hit = (unsigned)__ballot(hit_);
     return t_;
   };
   // the 8 x 16 bytes a lane needs of one (sample, view): four taps x this lane's 8 channels.
@@ -2045,11 +2049,13 @@ k_sem(gpn_sem_args_t a) {
       bl[l >> 1][l & 1] = lse;
     }
     const unsigned vis = live_of_mask(mv);
-    unsigned live = vis != 0 ? vis : all_views;
+    // an all-masked sample takes the uniform weight over EVERY view, but a view whose four taps all
+    // lie outside its map contributes exact zeros (grid_sample zero padding): skipped, same bits
+    unsigned live = vis != 0 ? vis : (all_views & tab.hit);
     unsigned live_n = 0;  // live views of the next sample
     if (s + 1 < S) {
       const unsigned vn = live_of_mask(mv_next);
-      live_n = vn != 0 ? vn : all_views;
+      live_n = vn != 0 ? vn : (all_views & tab_next.hit);
     }
     // hidden layer of attn_fc for all DEPTH layers of a (sample, view): 8*DEPTH floats, one per lane,
     // fetched one view ahead; every lane needs all of them, so they go through an LDS slot of the

@@ -800,7 +800,7 @@ def test_render_rays_stress_shape(dev, net, prec):
 
 
 # ------------------------------------------------------------------------------ ray generation (8(f) rank 1)
-@pytest.mark.parametrize("rig,mode", [("sparse", "bf16x3"), ("dense", "fp32")])
+@pytest.mark.parametrize("rig,mode", [("sparse", "bf16x3"), ("dense", "fp32"), ("stress", "bf16x3")])
 def test_full_size_properties(dev, rig, mode):
     """BASELINE.json configs[1] at full size (4096 rays, 48 + 16 samples, 10 views, 640x480 maps: too big
     for the CPU oracle in a test) through size-independent properties of the path:
@@ -810,22 +810,26 @@ def test_full_size_properties(dev, rig, mode):
     * linearity in the deep-semantic maps: doubling the maps doubles feats_out_3d
       exactly and leaves rgb / weights / depth untouched bit for bit.
     Both visibility regimes of the bench: the sparse rig (~41 % of the pairs visible,
-    most tiles skip views) and the dense rig (~96 %, nearly every view computed), one arithmetic mode each."""
+    most tiles skip views) and the dense rig (~96 %, nearly every view computed), one arithmetic mode each.
+    "stress" = BASELINE.json configs[4] at full size on one GPU: 16 views of 1296x968 images, 96 + 32
+    samples (a 96- and a 128-sample pass)."""
     import bench
     from gp_nerf_amd.render_ray import render_rays
-    scene, gnt, projector = bench.build(dev, rig=rig)
+    stress = rig == "stress"
+    scene, gnt, projector = bench.build_stress(dev) if stress else bench.build(dev, rig=rig)
+    NS, NI = (bench.STRESS["n_samples"], bench.STRESS["n_importance"]) if stress else (48, 16)
     gnt.precision = mode
     model = types.SimpleNamespace(net_coarse=gnt, net_fine=None)
     rb = bench.ray_chunk(scene, 0, 1, dev)
     sv = projector.prepare(rb["camera"], rb["src_rgbs"], rb["src_cameras"], scene.featmaps, scene.deep)
     from gp_nerf_amd import render_ray as rr
-    pts0, _ = rr.sample_along_camera_ray(rb["ray_o"], rb["ray_d"], rb["depth_range"], 48, inv_uniform=True, det=True)
+    pts0, _ = rr.sample_along_camera_ray(rb["ray_o"], rb["ray_d"], rb["depth_range"], NS, inv_uniform=True, det=True)
     vis_mean = float(projector.compute_fused(pts0, sv)[2].mean())
-    assert (vis_mean > 0.9) if rig == "dense" else (0.3 < vis_mean < 0.6), vis_mean
+    assert (vis_mean > 0.9) if rig == "dense" else (0.2 < vis_mean < 0.8), vis_mean
 
     def run(batch, deep):
-        return render_rays(batch, model, scene.featmaps, deep, projector, N_samples=48, inv_uniform=True,
-                           N_importance=16, det=True, ret_alpha=True, single_net=True)
+        return render_rays(batch, model, scene.featmaps, deep, projector, N_samples=NS, inv_uniform=True,
+                           N_importance=NI, det=True, ret_alpha=True, single_net=True)
 
     def part(lo, hi):
         b = dict(rb)
@@ -836,7 +840,7 @@ def test_full_size_properties(dev, rig, mode):
     R = rb["ray_o"].shape[0]
     assert R == 4096
     halves = [run(part(0, 1500), scene.deep), run(part(1500, R), scene.deep)]
-    for lvl, S in (("outputs_coarse", 48), ("outputs_fine", 64)):
+    for lvl, S in (("outputs_coarse", NS), ("outputs_fine", NS + NI)):
         for k in ("rgb", "depth", "weights", "feats_out", "feats_out_3d"):
             whole = full[lvl][k]
             joined = torch.cat([h[lvl][k] for h in halves], dim=0)

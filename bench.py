@@ -33,7 +33,8 @@ Prints ONE JSON line (rank 0):
                 literal "4096 rays x 64 samples x 10 views"), dense_visibility (5 cm / no-yaw rig, near
                 plane 1 m: ~96 % of the (sample, view) pairs visible instead of ~41 %), projector_standalone
                 (Projector.compute with the 512-channel gather materialised, B_proj of SURVEY 8(d)),
-                stress_shape (BASELINE configs[4] on one GPU: 16 views, 1296x968 images, 96 + 32 samples).
+                stress_shape (BASELINE configs[4] on one GPU: 16 views, 1296x968 images, 96 + 32 samples),
+                scannet_eval_view (BASELINE configs[2]: encoders + 76,800 rays + semantic head, seconds per view).
   cpu_baseline  the CPU oracle (a port of the reference path) on a bounded ray sample.
 """
 import argparse
@@ -232,7 +233,8 @@ def main():
     ap.add_argument("--only-timed", action="store_true",
                     help="skip the other arithmetic mode, the extra legs, the full-image run and the CPU baseline "
                          "(tools/profile_round.sh: the profiled kernels are then the timed workload only)")
-    ap.add_argument("--leg", default=None, choices=("single_pass_64", "dense_visibility", "projector_standalone", "stress_shape"),
+    ap.add_argument("--leg", default=None, choices=("single_pass_64", "dense_visibility", "projector_standalone", "stress_shape",
+                                                 "scannet_eval_view"),
                     help="run ONLY this leg as the timed workload (profiling aid; prints the leg's block)")
     a = ap.parse_args()
     if a.only_timed:
@@ -430,7 +432,8 @@ def main():
     if rank == 0 and world == 1 and not a.only_timed:
         legs = {name: run_leg(name, a, dev, scene, rb, net, model, projector, make_step, measure,
                               stage_breakdown, world, rank)
-                for name in ("single_pass_64", "dense_visibility", "projector_standalone", "stress_shape")}
+                for name in ("single_pass_64", "dense_visibility", "projector_standalone", "stress_shape",
+                             "scannet_eval_view")}
         net.precision = a.precision
 
     # secondary metric: seconds per full image through render_single_image, results
@@ -606,7 +609,60 @@ def run_leg(name, a, dev, scene, rb, net, model, projector, make_step, measure, 
         del sc, proj, rbs, r
         torch.cuda.empty_cache()
         return out
+    if name == "scannet_eval_view":
+        # BASELINE.json configs[2]: one ScanNet-shaped evaluation view through the whole chain of
+        # eval_gpnerf.py:172-206 -- ResUNet + FPN on the 10 source images, render_single_image over the
+        # 240x320 image (render_stride 1, chunk_size 2000 as in configs/gpnerf_scannet.txt), semantic
+        # head on the half-resolution feature image, label image.  Results on the host as the driver
+        # receives them.  Random-init encoders / head (torch default init), GNT as in the headline.
+        out = {"workload": "render_view: ResUNet+FPN encoders on 10 source images 320x240, 76,800 rays in chunks of "
+                           "2000, 48 + 16 samples, semantic head (20 classes + 1) and labels; seconds per view"}
+        view = scannet_view(dev)
+        for mode in ("fp32", "bf16x3"):
+            out[mode] = view(mode, repeats=3)
+        return out
     raise ValueError(name)
+
+
+def scannet_view(dev, chunk_size=2000):
+    """-> run(mode, repeats) for the scannet_eval_view leg (also used by the full-size test)."""
+    from gp_nerf_amd import synth
+    from gp_nerf_amd.eval_view import render_view
+    from gp_nerf_amd.model import GPNeRFModel
+    from gp_nerf_amd.projection import Projector
+    from gp_nerf_amd.sample_ray import RaySamplerSingleImage
+    torch.manual_seed(4321)
+    args = types.SimpleNamespace(netwidth=64, trans_depth=8, save_feature=False, semantic_model="fpn",
+                                 num_classes=20, coarse_feat_dim=32, fine_feat_dim=32, single_net=True,
+                                 N_importance=N_IMPORTANCE, N_samples=N_SAMPLES, inv_uniform=True, white_bkgd=False,
+                                 chunk_size=chunk_size, render_stride=1, local_rank=dev.index or 0, ckpt_path=None,
+                                 no_reload=True, rootdir="/nonexistent", expname="none", n_p=0)
+    model = GPNeRFModel(args)
+    model.net_coarse.load_state_dict(synth.gnt_state_dict())
+    sc = synth.scannet_scene(V=VIEWS, map_source="torch")
+    data = {"rgb": sc.src_rgbs[0, :1].clone(), "camera": sc.camera, "rgb_path": "synthetic", "true_depth": None,
+            "depth_mask": None, "depth_range": sc.depth_range, "src_rgbs": sc.src_rgbs, "src_cameras": sc.src_cameras}
+    sampler = RaySamplerSingleImage(data, dev, render_stride=1)
+    projector = Projector(dev)
+
+    def run(mode, repeats=1, chunk=None):
+        model.net_coarse.precision = mode
+        args.chunk_size = chunk or chunk_size
+        best, ret = None, None
+        for _ in range(repeats):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ret, _ = render_view(args, model, sampler, projector, render_stride=1, ret_alpha=True,
+                                 single_net=True, feats_out_3d=False)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        n = sc.H * sc.W
+        run.last = ret
+        return {"precision": mode, "seconds_per_view": best, "rays_per_sec": n / best, "rays": n,
+                "labels_shape": list(ret["outputs_fine"]["labels"].shape)}
+    run.model, run.sampler, run.projector, run.args = model, sampler, projector, args
+    return run
 
 
 def compare_with_cpu(scene, rb, projector, ret, want, nr, dev):

@@ -1040,6 +1040,67 @@ def test_checkpoint_roundtrip_and_render_view(dev, tmp_path):
     assert torch.equal(ret["outputs_coarse"]["labels"].cpu()[clear], lg[0].argmax(dim=0)[clear])
 
 
+def test_scannet_eval_view_full_size(dev):
+    """BASELINE.json configs[2] at full size (240x320 ScanNet-shaped view, 10 source views, 48 + 16 samples,
+    chunk_size 2000 as in configs/gpnerf_scannet.txt; too big for the CPU oracle in a test), the whole
+    render_view chain (reference eval_gpnerf.py:172-206) through its size-independent properties:
+    * shapes of the reference's return dictionary, everything finite;
+    * the label image is exactly the argmax of the logits the chain returns (21 classes);
+    * chunk invariance of the renderer on the encoders' maps: chunk_size 2000 (ragged last chunk) and
+      4096 give the same rgb / depth / feats_out, hence logits / labels, bit for bit.  (The encoders are
+      library convolutions; two calls of them on the same images differ in the last bits on this
+      stack, so the maps are computed once for this part.)
+    * the two arithmetic modes agree on the logits within the parity bar and on every label whose
+      top-2 margin exceeds the logit difference."""
+    import bench
+    from gp_nerf_amd.render_image import render_single_image
+    from gp_nerf_amd.semantic_branch import semantic_labels
+    view = bench.scannet_view(dev)
+    H, W = 240, 320
+    view("fp32")
+    a = view.last
+    for lvl in ("outputs_coarse", "outputs_fine"):
+        assert tuple(a[lvl]["rgb"].shape) == (H, W, 3) and tuple(a[lvl]["depth"].shape) == (H, W)
+        assert tuple(a[lvl]["sems"].shape) == (1, H, W, 21) and tuple(a[lvl]["labels"].shape) == (H, W)
+        assert a[lvl]["labels"].dtype == torch.int64
+        for k in ("rgb", "depth", "sems"):
+            assert bool(torch.isfinite(a[lvl][k]).all()), (lvl, k)
+        assert torch.equal(a[lvl]["labels"].cpu(), a[lvl]["sems"].cpu().argmax(dim=-1)[0])
+    model, sampler, projector = view.model, view.sampler, view.projector
+    rb = sampler.get_all()
+    with torch.no_grad():
+        coarse, _, deep_in = model.feature_net(rb["src_rgbs"].squeeze(0).permute(0, 3, 1, 2))
+        deep = model.feature_fpn(deep_in)
+
+    def image(mode, chunk):
+        model.net_coarse.precision = mode
+        r = render_single_image(ray_sampler=sampler, ray_batch=rb, model=model, projector=projector,
+                                chunk_size=chunk, N_samples=48, inv_uniform=True, det=True, N_importance=16,
+                                white_bkgd=False, render_stride=1, featmaps=coarse, deep_semantics=deep,
+                                ret_alpha=True, single_net=True, feats_out_3d=False)
+        with torch.no_grad():
+            f = r["outputs_coarse"]["feats_out"][::2, ::2, :].permute(2, 0, 1).unsqueeze(0).to(dev)
+            r["logits"] = model.sem_seg_head(f, None, None)
+        return r
+
+    x, y = image("fp32", 2000), image("fp32", 4096)
+    for lvl in ("outputs_coarse", "outputs_fine"):
+        for k in ("rgb", "depth", "feats_out"):
+            assert torch.equal(x[lvl][k].view(torch.int32), y[lvl][k].view(torch.int32)), (lvl, k)
+    z = image("bf16x3", 2000)
+    for k in ("rgb", "depth", "feats_out"):
+        assert rel(z["outputs_coarse"][k], x["outputs_coarse"][k].cpu()) < TOL, k
+    lx, lz = x["logits"].cpu(), z["logits"].cpu()
+    diff = float((lx - lz).abs().max())
+    assert diff < TOL * max(1.0, float(lx.abs().max())), diff
+    top2 = lx[0].topk(2, dim=0).values
+    clear = (top2[0] - top2[1]) > 4 * diff
+    assert torch.equal(semantic_labels(x["logits"]).cpu()[clear], semantic_labels(z["logits"]).cpu()[clear])
+    print("scannet view: fp32 vs bf16x3 logits differ by %.2e (scale %.2f); %.4f of the pixels have a top-2 margin above 4x that"
+          % (diff, float(lx.abs().max()), float(clear.float().mean())))
+    assert float(clear.float().mean()) > 0.9
+
+
 def test_sem_head_direct_vs_oracle(dev):
     """a15 at the reference's own size: device head vs the CPU restatement on a [1,512,120,160] feature
     image, 21 classes (reference semantic_branch.py:89-107; 120x160 is hard-coded there, :95).  Logits

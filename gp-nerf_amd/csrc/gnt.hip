@@ -478,7 +478,7 @@ k_proj_rgbfeat(gpn_project_args_t a, gpn_linear_t fc0, gpn_linear_t fc2, float* 
           tab.fw[2][lane] = (tf.vy1 && tf.vx0) ? tf.sw : 0.0f, tab.fw[3][lane] = (tf.vy1 && tf.vx1) ? tf.se : 0.0f;
           tab.rw[0][lane] = (tr.vy0 && tr.vx0) ? tr.nw : 0.0f, tab.rw[1][lane] = (tr.vy0 && tr.vx1) ? tr.ne : 0.0f;
           tab.rw[2][lane] = (tr.vy1 && tr.vx0) ? tr.sw : 0.0f, tab.rw[3][lane] = (tr.vy1 && tr.vx1) ? tr.se : 0.0f;
-          if ((wr >> v) & 1u)  // dead pairs are never read by gpn_view_attn: their 9 divisions are skipped
+          if (a.ray_diff != nullptr && ((wr >> v) & 1u))  // dead pairs are never read by gpn_view_attn: their 9 divisions are skipped
             *reinterpret_cast<float4*>(a.ray_diff + ((size_t)n * V + v) * 4) =
                 gpn_ray_diff(px, py, pz, a.qry_pos[0], a.qry_pos[1], a.qry_pos[2], sPos[v * 3 + 0],
                              sPos[v * 3 + 1], sPos[v * 3 + 2]);
@@ -708,12 +708,44 @@ k_view_fold(gpn_view_layer_t Lw, float* __restrict__ out) {
   }
 }
 
+// ray_diff in the order k_view_attn consumes it: out[((tile * V + v) * 4 + c) * 16 + j] = component c of
+// the pair (point of slot 16 tile + j, view v); slots past N repeat the last point.  Source: the
+// [N,V,4] array of the caller (rd != nullptr), else compute_angle itself from the points and the camera
+// centres (proj_common.h: the very function the projector kernels call, same bits).
+__global__ void __launch_bounds__(256)
+k_rd_pack(const float* __restrict__ rd, const float* __restrict__ xyz, float qx, float qy, float qz,
+          const float* __restrict__ src_pos, const int* __restrict__ perm, long long N, int V,
+          float* __restrict__ out) {
+  const long long total = ((N + 15) >> 4) * V * 16;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int j = (int)(idx & 15);
+    const long long tv = idx >> 4;  // tile * V + v
+    const long long tile = tv / V;
+    const int v = (int)(tv - tile * V);
+    const long long slot = tile * 16 + j, sc = slot < N ? slot : N - 1;
+    const long long n = perm != nullptr ? perm[sc] : sc;
+    float4 r;
+    if (rd != nullptr) {
+      r = *reinterpret_cast<const float4*>(rd + ((size_t)n * V + v) * 4);
+    } else {
+      r = gpn_ray_diff(xyz[n * 3 + 0], xyz[n * 3 + 1], xyz[n * 3 + 2], qx, qy, qz,
+                       src_pos[v * 3 + 0], src_pos[v * 3 + 1], src_pos[v * 3 + 2]);
+    }
+    float* o = out + (size_t)tv * 64 + j;
+    o[0] = r.x, o[16] = r.y, o[32] = r.z, o[48] = r.w;
+  }
+}
+
 template <bool SPL, bool FOLD>
 __global__ void __launch_bounds__(VA_TPB)
 k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __restrict__ feat,
             const float* __restrict__ ray_diff, const float* __restrict__ mask,
             const int* __restrict__ perm, long long N, int V, float* __restrict__ q_out,
-            float* __restrict__ hidden, int hidden_ld, float* __restrict__ stats, int stats_ld) {
+            float* __restrict__ hidden, int hidden_ld, float* __restrict__ stats, int stats_ld,
+            int rd_packed) {
+  // rd_packed != 0: `ray_diff` is the tile-major image written by k_rd_pack ([tile][view][component][16
+  // points of the tile, in slot order]): the 64 floats of a (tile, view) pair are ONE contiguous 256-byte
+  // run (two whole lines) instead of 16 sixteen-byte entries in 16 different 64-byte sectors.
   const ViewLds L = view_lds<SPL>(smem);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (tile loop, LDS-DMA base)
@@ -782,11 +814,12 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
   // 4*half: the rotation makes the read-back below bank-conflict free.
   const int jj8 = lane >> 3, r8 = lane & 7;
   const int cA = (r8 - (jj8 >> 1)) & 7, cB = (r8 - (jj8 >> 1) - 4) & 7;
-  auto dma_pair = [&](int nn, int vv, unsigned sl) {
+  auto dma_pair = [&](int nn, long long tile_, int vv, unsigned sl) {
     const int nA = __shfl(nn, jj8), nB = __shfl(nn, 8 + jj8);
     const char* fa = reinterpret_cast<const char*>(feat) + ((size_t)nA * V + vv) * (C64 * 4) + cA * 16;
     const char* fb = reinterpret_cast<const char*>(feat) + ((size_t)nB * V + vv) * (C64 * 4) + cB * 16;
-    const char* ra = reinterpret_cast<const char*>(ray_diff) + ((size_t)nn * V + vv) * 16 + g * 4;
+    const char* ra = reinterpret_cast<const char*>(ray_diff) +
+                     (rd_packed ? ((size_t)tile_ * V + vv) * 256 + lane * 4 : ((size_t)nn * V + vv) * 16 + g * 4);
     // instruction offsets apply to the global AND the LDS address: M0 is compensated per piece
     const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane(ring_lds + sl * VA_SLOT_BYTES);
     const unsigned m0 = base, m1 = base + 1024, m2 = base + 2048 - 128, m3 = base + 3072 - 128, m4 = base + 4096;
@@ -857,11 +890,11 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may still land in the slots
     par = 0;
     const int v0 = __builtin_ctz(live);
-    dma_pair(n, v0, 0);
+    dma_pair(n, tile, v0, 0);
     const unsigned rest = live & (live - 1);
-    if (rest) dma_pair(n, __builtin_ctz(rest), 1);
-    else if (live1) dma_pair(n1, __builtin_ctz(live1), 1);
-    else dma_pair(n, v0, 1);  // no further pair: keep the op count
+    if (rest) dma_pair(n, tile, __builtin_ctz(rest), 1);
+    else if (live1) dma_pair(n1, tile + tstride, __builtin_ctz(live1), 1);
+    else dma_pair(n, tile, v0, 1);  // no further pair: keep the op count
   };
   f4 xq[4];
   {  // two-phase staging (gnt_mfma.h): every global load first, then the LDS images
@@ -1010,7 +1043,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
           int t2, v2;
           pair_plus2(live, t2, v2);
           const int nn = t2 == 1 ? n1 : (t2 == 2 ? n2 : n);
-          dma_pair(nn, t2 < 0 ? v : v2, par);
+          dma_pair(nn, tile + (t2 > 0 ? t2 : 0) * tstride, t2 < 0 ? v : v2, par);
           par ^= 1u;
         }
         f4 vp[4], a[4];  // vp = v + pos (the value that is attended over)
@@ -2305,8 +2338,8 @@ extern "C" int gpn_project_rgbfeat(const gpn_project_args_t* a, const gpn_linear
   GPN_REQUIRE(a, "gpn_project_rgbfeat: null args");
   if (a->N == 0) return GPN_OK;  // empty batch
   GPN_REQUIRE(fc0 && fc2 && feat && q0, "gpn_project_rgbfeat: null pointer");
-  GPN_REQUIRE(a->xyz && a->proj && a->src_pos && a->rgb && a->feat && a->mask && a->ray_diff,
-              "gpn_project_rgbfeat: xyz, proj, src_pos, rgb, feat, mask and ray_diff are required");
+  GPN_REQUIRE(a->xyz && a->proj && a->src_pos && a->rgb && a->feat && a->mask,
+              "gpn_project_rgbfeat: xyz, proj, src_pos, rgb, feat and mask are required");
   GPN_REQUIRE(!a->rgb_feat && !a->deep_out && !a->pix && !a->taps && !a->front,
               "gpn_project_rgbfeat: rgb_feat / deep_out / pix / taps / front are outputs of gpn_project_gather only");
   GPN_REQUIRE(a->N > 0 && a->V >= 1 && a->V <= GPN_MAX_VIEWS, "gpn_project_rgbfeat: need 1 <= V <= %d (got %d)",
@@ -2322,7 +2355,7 @@ extern "C" int gpn_project_rgbfeat(const gpn_project_args_t* a, const gpn_linear
   GPN_REQUIRE(a->img_h > 1.0f && a->img_w > 1.0f, "gpn_project_rgbfeat: bad image size");
   GPN_REQUIRE(fc0->w, "gpn_project_rgbfeat: null weight");
   REQ_LIN(*fc2, "gpn_project_rgbfeat.fc2");
-  GPN_REQUIRE(aligned16(feat) && aligned16(q0) && aligned16(a->feat) && aligned16(a->ray_diff),
+  GPN_REQUIRE(aligned16(feat) && aligned16(q0) && aligned16(a->feat) && (!a->ray_diff || aligned16(a->ray_diff)),
               "gpn_project_rgbfeat: feat, q0, the feature maps and ray_diff must be 16-byte aligned");
   const bool spl = precision == GPN_PREC_BF16X3;
   const size_t lds = proj_rgbfeat_lds(spl);
@@ -2372,10 +2405,10 @@ extern "C" int gpn_view_fold(const gpn_view_layer_t* L, float* out, gpn_stream_t
   return GPN_OK;
 }
 
-extern "C" int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const float* feat,
-                             const float* ray_diff, const float* mask, const int32_t* perm, int N,
-                             int V, float* q_out, float* hidden, int hidden_ld, float* stats,
-                             int stats_ld, int precision, gpn_stream_t stream) {
+static int view_attn_launch(const gpn_view_layer_t* L, const float* q_in, const float* feat,
+                            const float* ray_diff, int rd_packed, const float* mask, const int32_t* perm, int N,
+                            int V, float* q_out, float* hidden, int hidden_ld, float* stats,
+                            int stats_ld, int precision, gpn_stream_t stream) {
   GPN_REQUIRE_PREC(precision, "gpn_view_attn");
   if (N == 0) return GPN_OK;  // empty batch (pointers may be null)
   GPN_REQUIRE(L && q_in && feat && ray_diff && mask && q_out, "gpn_view_attn: null pointer");
@@ -2409,17 +2442,40 @@ extern "C" int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const
   hipStream_t st = (hipStream_t)stream;
   if (fold && spl)
     hipLaunchKernelGGL((k_view_attn<true, true>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
-                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld);
+                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, rd_packed);
   else if (fold)
     hipLaunchKernelGGL((k_view_attn<false, true>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
-                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld);
+                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, rd_packed);
   else if (spl)
     hipLaunchKernelGGL((k_view_attn<true, false>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
-                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld);
+                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, rd_packed);
   else
     hipLaunchKernelGGL((k_view_attn<false, false>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
-                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld);
+                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, rd_packed);
   GPN_LAUNCH_CHECK("k_view_attn");
+  return GPN_OK;
+}
+
+extern "C" int gpn_view_attn(const gpn_view_layer_t* L, const float* q_in, const float* feat,
+                             const float* ray_diff, const float* mask, const int32_t* perm, int N,
+                             int V, float* q_out, float* hidden, int hidden_ld, float* stats,
+                             int stats_ld, int precision, gpn_stream_t stream) {
+  return view_attn_launch(L, q_in, feat, ray_diff, 0, mask, perm, N, V, q_out, hidden, hidden_ld, stats, stats_ld,
+                          precision, stream);
+}
+
+// ray_diff re-laid for k_view_attn (k_rd_pack); `rd` given: gather, else computed from the geometry
+static int rd_pack_launch(const float* rd, const float* xyz, const float* qry_pos, const float* src_pos,
+                          const int32_t* perm, int N, int V, float* out, gpn_stream_t stream) {
+  GPN_REQUIRE(out && (rd || (xyz && qry_pos && src_pos)), "k_rd_pack: null pointer");
+  const float qx = qry_pos ? qry_pos[0] : 0.f, qy = qry_pos ? qry_pos[1] : 0.f, qz = qry_pos ? qry_pos[2] : 0.f;
+  GPN_REQUIRE(aligned16(rd) && aligned16(out), "k_rd_pack: ray_diff must be 16-byte aligned");
+  const long long total = (((long long)N + 15) >> 4) * V * 16;
+  const int grid = (int)std::min<long long>((total + 255) / 256, 65535);
+  GpnStageTimer timer_(GPN_ST_VIS_ORDER, (hipStream_t)stream);
+  hipLaunchKernelGGL(k_rd_pack, dim3(grid), dim3(256), 0, (hipStream_t)stream, rd, xyz, qx, qy, qz, src_pos, perm,
+                     (long long)N, V, out);
+  GPN_LAUNCH_CHECK("k_rd_pack");
   return GPN_OK;
 }
 
@@ -2624,7 +2680,7 @@ static GntWs gnt_ws_layout(int R, int S, int V, int depth) {
   w.pre = o, o += align_up((size_t)R * GPN_SEM * f);
   w.perm = o, o += align_up(2 * N * sizeof(int));  // points in slot order | their visibility bits
   w.vis_scratch = o, o += align_up(2 * VIS_BINS * sizeof(int));
-  w.rdiff = o, o += align_up(N * V * 4 * f);  // gpn_render_pass: ray_diff / mask of the fused projector
+  w.rdiff = o, o += align_up(((N + 15) / 16 * 16) * V * 4 * f);  // ray_diff in k_view_attn's tile order (k_rd_pack)
   w.mask = o, o += align_up(N * V * f);
   w.total = o;
   return w;
@@ -2672,13 +2728,17 @@ static int gnt_forward_impl(const gpn_gnt_weights_t* W, const gpn_project_args_t
   if (proj) {
     gpn_project_args_t pa = *proj;
     pa.xyz = pts, pa.N = (int)N;
-    if (!pa.ray_diff) pa.ray_diff = reinterpret_cast<float*>(ws + L.rdiff);
+    // (pa.ray_diff stays null unless the caller wants the [N,V,4] array: k_rd_pack computes its own)
     if (!pa.mask) pa.mask = reinterpret_cast<float*>(ws + L.mask);
     GPN_REQUIRE(pa.V == V && pa.feat_c == W->in_feat_ch, "gpn_render_pass: proj.V / proj.feat_c do not match");
     if ((rc = gpn_project_rgbfeat(&pa, &W->rgbfeat0, &W->rgbfeat2, feat, q, prec, stream))) return rc;
-    ray_diff = pa.ray_diff, mask = pa.mask;
+    mask = pa.mask;
   }
   if ((rc = gpn_vis_order(mask, (int)N, V, perm, ws + L.vis_scratch, stream))) return rc;
+  float* rdp = reinterpret_cast<float*>(ws + L.rdiff);
+  if ((rc = rd_pack_launch(proj ? nullptr : ray_diff, pts, proj ? proj->qry_pos : nullptr,
+                           proj ? proj->src_pos : nullptr, perm, (int)N, V, rdp, stream)))
+    return rc;
   if ((rc = gpn_posenc(pts, ray_d, R, S, emb, emb_ray, stream))) return rc;
   // (mask given: the feature rows of masked pairs, which gpn_view_attn never uses, are not stored)
   if (!proj &&
@@ -2692,8 +2752,7 @@ static int gnt_forward_impl(const gpn_gnt_weights_t* W, const gpn_project_args_t
     float* ab = sem ? reinterpret_cast<float*>(ws + L.abar) + l * 4 : nullptr;
     const gpn_view_layer_t* vl = &W->view[l];
     const gpn_ray_layer_t* rl = &W->ray[l];
-    if ((rc = gpn_view_attn(vl, q, feat, ray_diff, mask, perm, (int)N, V, q, hd, D * 8, st, D * C64,
-                            prec, stream)))
+    if ((rc = view_attn_launch(vl, q, feat, rdp, 1, mask, perm, (int)N, V, q, hd, D * 8, st, D * C64, prec, stream)))
       return rc;
     if ((rc = gpn_ff(vl->ff_norm_w, vl->ff_norm_b, &vl->ff1, &vl->ff2, q, (int)N, q, prec, stream))) return rc;
     if (l % 2 == 0)

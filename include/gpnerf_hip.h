@@ -155,7 +155,7 @@ typedef struct {
 
 /* Projector.compute (without the deep-semantic gather) fused with rgbfeat_fc + max over views, reference
  * gpnerf/projection.py:31-139 + transformer_network.py:309-311: the fast path of render_rays.  Same
- * arguments as gpn_project_gather (a->mask and a->ray_diff required; rgb_feat / deep_out / pix / taps /
+ * arguments as gpn_project_gather (a->mask required, a->ray_diff optional; rgb_feat / deep_out / pix / taps /
  * front must be NULL) and the outputs of gpn_rgbfeat: feat [N,V,C] in the layout of `precision`, q0 [N,C].
  * The [N,V,3+F] tensor is never formed; pairs whose gathered row is exactly zero (every bilinear tap
  * outside both maps) take the constant row fc2(relu(fc0.bias)) without a gather or an MLP evaluation.

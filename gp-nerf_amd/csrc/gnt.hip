@@ -349,10 +349,34 @@ struct PrTab {  // per wave: 4 views x 16 points
   float fw[4][64], rw[4][64];          // nw ne sw se; 0 for a tap outside the map
 };
 
+// Visibility masks alone (projection.py:31-55, :99-104): the pass gpn_vis_order needs BEFORE the fused
+// kernel when that kernel is to write its rows in k_view_attn's tile order.  Same two functions as the
+// pre-pass of k_proj_rgbfeat: same bits.
+__global__ void __launch_bounds__(256)
+k_proj_mask(gpn_project_args_t a) {
+  __shared__ float sP[GPN_MAX_VIEWS * 12];
+  const int V = a.V;
+  for (int i = threadIdx.x; i < V * 12; i += 256) sP[i] = a.proj[(i / 12) * 16 + (i % 12)];
+  __syncthreads();
+  for (long long n = (long long)blockIdx.x * 256 + threadIdx.x; n < a.N; n += (long long)gridDim.x * 256) {
+    const float px = a.xyz[n * 3 + 0], py = a.xyz[n * 3 + 1], pz = a.xyz[n * 3 + 2];
+    for (int v = 0; v < V; ++v) {
+      const GpnPix pp = gpn_project(sP + v * 12, px, py, pz);
+      a.mask[(size_t)n * V + v] = (pp.front && gpn_inbound(pp.px, pp.py, a.img_h, a.img_w)) ? 1.0f : 0.0f;
+    }
+  }
+}
+
+// perm != nullptr: tile t of this kernel = slots 16 t .. 16 t + 15 of gpn_vis_order (the tiles of
+// k_view_attn), the masks are already in a.mask (k_proj_mask) and are not written again.
+// tiled != 0: the feature row of (slot 16 t + j, view v) goes to feat[((t V + v) 16 + j) 64] -- the 16 rows
+// of a (tile, view) pair are one contiguous 4 KB block, read back by k_view_attn as whole sequential
+// lines -- and, with rdp != nullptr, its ray_diff to the tile-major image of k_rd_pack.  Slots past N
+// repeat the last slot's point (rows written, q0 not).
 template <bool SPL>
 __global__ void __launch_bounds__(PR_TPB)
 k_proj_rgbfeat(gpn_project_args_t a, gpn_linear_t fc0, gpn_linear_t fc2, float* __restrict__ feat,
-               float* __restrict__ q0) {
+               float* __restrict__ q0, const int* __restrict__ perm, float* __restrict__ rdp, int tiled) {
   float* W0 = smem;
   float* W2 = W0 + wimg_floats(SPL, 64, 3, RF_LD0);
   float* b0 = W2 + wimg_floats(SPL, 64, 4, LDW);
@@ -420,8 +444,8 @@ k_proj_rgbfeat(gpn_project_args_t a, gpn_linear_t fc0, gpn_linear_t fc2, float* 
     }
     lin<SPL, 4, 4>(W2, LDW, h, y, lane);
   };
-  auto store_row = [&](long long n, int v, const f4* y) {
-    float* row = feat + ((size_t)n * V + v) * C64;
+  auto store_row = [&](long long n, long long tile_, int v, const f4* y) {
+    float* row = feat + (tiled ? (((size_t)tile_ * V + v) * 16 + (lane & 15)) : ((size_t)n * V + v)) * C64;
     if constexpr (SPL) {
       store_feat_split(row, y, g);
     } else {
@@ -438,21 +462,23 @@ k_proj_rgbfeat(gpn_project_args_t a, gpn_linear_t fc0, gpn_linear_t fc2, float* 
   const int fw_ = a.feat_w, fh_ = a.feat_h, rw_ = a.rgb_w, rh_ = a.rgb_h;
 
   for (long long tile = (long long)blockIdx.x * (PR_TPB / 64) + wave; tile < ntiles; tile += tstride) {
-    const long long n = tile * 16 + j;
-    const bool valid = n < N;
-    const long long nc = valid ? n : N - 1;
-    const float px = a.xyz[nc * 3 + 0], py = a.xyz[nc * 3 + 1], pz = a.xyz[nc * 3 + 2];
+    const long long slot = tile * 16 + j;
+    const bool valid = slot < N;
+    const long long sc = valid ? slot : N - 1;
+    const long long n = perm != nullptr ? perm[sc] : sc;  // the point of this lane
+    const bool real = valid || tiled != 0;                // tiled: padding slots carry the last point's rows
+    const float px = a.xyz[n * 3 + 0], py = a.xyz[n * 3 + 1], pz = a.xyz[n * 3 + 2];
     // ---- pre-pass: masks of every view
     unsigned vis = 0;
     for (int v = g; v < V; v += 4) {
       const GpnPix pp = gpn_project(sP + v * 12, px, py, pz);
       const bool m = pp.front && gpn_inbound(pp.px, pp.py, a.img_h, a.img_w);
-      if (valid) a.mask[(size_t)n * V + v] = m ? 1.0f : 0.0f;
+      if (valid && perm == nullptr) a.mask[(size_t)n * V + v] = m ? 1.0f : 0.0f;
       vis |= (m ? 1u : 0u) << v;
     }
     vis |= __shfl_xor(vis, 16);
     vis |= __shfl_xor(vis, 32);
-    const unsigned wr = valid ? (vis != 0 ? vis : all_views) : 0u;  // rows gpn_view_attn reads
+    const unsigned wr = real ? (vis != 0 ? vis : all_views) : 0u;  // rows gpn_view_attn reads
     f4 qmax[4];
 #pragma unroll
     for (int M = 0; M < 4; ++M) qmax[M] = f4_splat(-INFINITY);
@@ -468,7 +494,7 @@ k_proj_rgbfeat(gpn_project_args_t a, gpn_linear_t fc0, gpn_linear_t fc2, float* 
           const GpnTaps tr = gpn_taps(pp.px, pp.py, a.img_h, a.img_w, rh_, rw_);
           const bool any_f = (tf.vx0 || tf.vx1) && (tf.vy0 || tf.vy1);
           const bool any_r = (tr.vx0 || tr.vx1) && (tr.vy0 || tr.vy1);
-          zero_row = !valid || !(any_f || any_r);
+          zero_row = !real || !(any_f || any_r);
           auto cl = [](int c, int hi) { return min(max(c, 0), hi); };
           tab.fx[lane] = cl(tf.x0, fw_ - 1) | (cl(tf.x0 + 1, fw_ - 1) << 16);
           tab.fy[lane] = cl(tf.y0, fh_ - 1) | (cl(tf.y0 + 1, fh_ - 1) << 16);
@@ -478,10 +504,15 @@ k_proj_rgbfeat(gpn_project_args_t a, gpn_linear_t fc0, gpn_linear_t fc2, float* 
           tab.fw[2][lane] = (tf.vy1 && tf.vx0) ? tf.sw : 0.0f, tab.fw[3][lane] = (tf.vy1 && tf.vx1) ? tf.se : 0.0f;
           tab.rw[0][lane] = (tr.vy0 && tr.vx0) ? tr.nw : 0.0f, tab.rw[1][lane] = (tr.vy0 && tr.vx1) ? tr.ne : 0.0f;
           tab.rw[2][lane] = (tr.vy1 && tr.vx0) ? tr.sw : 0.0f, tab.rw[3][lane] = (tr.vy1 && tr.vx1) ? tr.se : 0.0f;
-          if (a.ray_diff != nullptr && ((wr >> v) & 1u))  // dead pairs are never read by gpn_view_attn: their 9 divisions are skipped
-            *reinterpret_cast<float4*>(a.ray_diff + ((size_t)n * V + v) * 4) =
-                gpn_ray_diff(px, py, pz, a.qry_pos[0], a.qry_pos[1], a.qry_pos[2], sPos[v * 3 + 0],
-                             sPos[v * 3 + 1], sPos[v * 3 + 2]);
+          if ((a.ray_diff != nullptr || rdp != nullptr) && ((wr >> v) & 1u)) {  // dead pairs are never read by gpn_view_attn: their 9 divisions are skipped
+            const float4 r4 = gpn_ray_diff(px, py, pz, a.qry_pos[0], a.qry_pos[1], a.qry_pos[2], sPos[v * 3 + 0],
+                                           sPos[v * 3 + 1], sPos[v * 3 + 2]);
+            if (a.ray_diff != nullptr && valid) *reinterpret_cast<float4*>(a.ray_diff + ((size_t)n * V + v) * 4) = r4;
+            if (rdp != nullptr) {
+              float* o = rdp + ((size_t)tile * V + v) * 64 + j;
+              o[0] = r4.x, o[16] = r4.y, o[32] = r4.z, o[48] = r4.w;
+            }
+          }
         }
       }
       const unsigned long long zb = __ballot(zero_row);  // bit 16 g + j
@@ -521,7 +552,7 @@ k_proj_rgbfeat(gpn_project_args_t a, gpn_linear_t fc0, gpn_linear_t fc2, float* 
           }
           mlp(x, y);
         }
-        if ((wr >> v) & 1u) store_row(n, v, y);
+        if ((wr >> v) & 1u) store_row(n, tile, v, y);
 #pragma unroll
         for (int M = 0; M < 4; ++M) qmax[M] = f4_max(qmax[M], y[M]);
       }
@@ -742,10 +773,13 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
             const float* __restrict__ ray_diff, const float* __restrict__ mask,
             const int* __restrict__ perm, long long N, int V, float* __restrict__ q_out,
             float* __restrict__ hidden, int hidden_ld, float* __restrict__ stats, int stats_ld,
-            int rd_packed) {
-  // rd_packed != 0: `ray_diff` is the tile-major image written by k_rd_pack ([tile][view][component][16
+            int layout) {
+  // layout & 1: `ray_diff` is the tile-major image written by k_rd_pack ([tile][view][component][16
   // points of the tile, in slot order]): the 64 floats of a (tile, view) pair are ONE contiguous 256-byte
   // run (two whole lines) instead of 16 sixteen-byte entries in 16 different 64-byte sectors.
+  // layout & 2: `feat` is tile-major too ([tile][view][16 slots][64], written by the fused projector):
+  // the 16 rows of a pair are one sequential 4 KB block instead of 16 random rows.
+  const int rd_packed = layout & 1, feat_tiled = layout & 2;
   const ViewLds L = view_lds<SPL>(smem);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (tile loop, LDS-DMA base)
@@ -816,8 +850,10 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
   const int cA = (r8 - (jj8 >> 1)) & 7, cB = (r8 - (jj8 >> 1) - 4) & 7;
   auto dma_pair = [&](int nn, long long tile_, int vv, unsigned sl) {
     const int nA = __shfl(nn, jj8), nB = __shfl(nn, 8 + jj8);
-    const char* fa = reinterpret_cast<const char*>(feat) + ((size_t)nA * V + vv) * (C64 * 4) + cA * 16;
-    const char* fb = reinterpret_cast<const char*>(feat) + ((size_t)nB * V + vv) * (C64 * 4) + cB * 16;
+    const size_t rowA = feat_tiled ? ((size_t)tile_ * V + vv) * 16 + jj8 : (size_t)nA * V + vv;
+    const size_t rowB = feat_tiled ? ((size_t)tile_ * V + vv) * 16 + 8 + jj8 : (size_t)nB * V + vv;
+    const char* fa = reinterpret_cast<const char*>(feat) + rowA * (C64 * 4) + cA * 16;
+    const char* fb = reinterpret_cast<const char*>(feat) + rowB * (C64 * 4) + cB * 16;
     const char* ra = reinterpret_cast<const char*>(ray_diff) +
                      (rd_packed ? ((size_t)tile_ * V + vv) * 256 + lane * 4 : ((size_t)nn * V + vv) * 16 + g * 4);
     // instruction offsets apply to the global AND the LDS address: M0 is compensated per piece
@@ -2331,9 +2367,9 @@ static size_t proj_rgbfeat_lds(bool spl) {
                           GPN_MAX_VIEWS * 15) + (PR_TPB / 64) * sizeof(PrTab);
 }
 
-extern "C" int gpn_project_rgbfeat(const gpn_project_args_t* a, const gpn_linear_t* fc0,
-                                   const gpn_linear_t* fc2, float* feat, float* q0, int precision,
-                                   gpn_stream_t stream) {
+static int proj_rgbfeat_launch(const gpn_project_args_t* a, const gpn_linear_t* fc0,
+                               const gpn_linear_t* fc2, float* feat, float* q0, const int32_t* perm, float* rdp,
+                               int tiled, int precision, gpn_stream_t stream) {
   GPN_REQUIRE_PREC(precision, "gpn_project_rgbfeat");
   GPN_REQUIRE(a, "gpn_project_rgbfeat: null args");
   if (a->N == 0) return GPN_OK;  // empty batch
@@ -2366,11 +2402,28 @@ extern "C" int gpn_project_rgbfeat(const gpn_project_args_t* a, const gpn_linear
   GpnStageTimer timer_(GPN_ST_PROJ_RGBFEAT, (hipStream_t)stream);
   if (spl)
     hipLaunchKernelGGL(k_proj_rgbfeat<true>, dim3(grid), dim3(PR_TPB), lds, (hipStream_t)stream, *a, *fc0, *fc2,
-                       feat, q0);
+                       feat, q0, perm, rdp, tiled);
   else
     hipLaunchKernelGGL(k_proj_rgbfeat<false>, dim3(grid), dim3(PR_TPB), lds, (hipStream_t)stream, *a, *fc0, *fc2,
-                       feat, q0);
+                       feat, q0, perm, rdp, tiled);
   GPN_LAUNCH_CHECK("k_proj_rgbfeat");
+  return GPN_OK;
+}
+
+extern "C" int gpn_project_rgbfeat(const gpn_project_args_t* a, const gpn_linear_t* fc0,
+                                   const gpn_linear_t* fc2, float* feat, float* q0, int precision,
+                                   gpn_stream_t stream) {
+  return proj_rgbfeat_launch(a, fc0, fc2, feat, q0, nullptr, nullptr, 0, precision, stream);
+}
+
+// masks of every (point, view) pair: the pre-pass of the tile-ordered fused projector
+static int proj_mask_launch(const gpn_project_args_t* a, gpn_stream_t stream) {
+  GPN_REQUIRE(a && a->xyz && a->proj && a->mask, "k_proj_mask: null pointer");
+  GPN_REQUIRE(a->N > 0 && a->V >= 1 && a->V <= GPN_MAX_VIEWS, "k_proj_mask: bad shape");
+  const int grid = (int)std::min<long long>(((long long)a->N + 255) / 256, 65535);
+  GpnStageTimer timer_(GPN_ST_PROJ_RGBFEAT, (hipStream_t)stream);
+  hipLaunchKernelGGL(k_proj_mask, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  GPN_LAUNCH_CHECK("k_proj_mask");
   return GPN_OK;
 }
 
@@ -2406,7 +2459,7 @@ extern "C" int gpn_view_fold(const gpn_view_layer_t* L, float* out, gpn_stream_t
 }
 
 static int view_attn_launch(const gpn_view_layer_t* L, const float* q_in, const float* feat,
-                            const float* ray_diff, int rd_packed, const float* mask, const int32_t* perm, int N,
+                            const float* ray_diff, int layout, const float* mask, const int32_t* perm, int N,
                             int V, float* q_out, float* hidden, int hidden_ld, float* stats,
                             int stats_ld, int precision, gpn_stream_t stream) {
   GPN_REQUIRE_PREC(precision, "gpn_view_attn");
@@ -2442,16 +2495,16 @@ static int view_attn_launch(const gpn_view_layer_t* L, const float* q_in, const 
   hipStream_t st = (hipStream_t)stream;
   if (fold && spl)
     hipLaunchKernelGGL((k_view_attn<true, true>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
-                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, rd_packed);
+                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, layout);
   else if (fold)
     hipLaunchKernelGGL((k_view_attn<false, true>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
-                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, rd_packed);
+                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, layout);
   else if (spl)
     hipLaunchKernelGGL((k_view_attn<true, false>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
-                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, rd_packed);
+                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, layout);
   else
     hipLaunchKernelGGL((k_view_attn<false, false>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
-                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, rd_packed);
+                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, layout);
   GPN_LAUNCH_CHECK("k_view_attn");
   return GPN_OK;
 }
@@ -2671,7 +2724,7 @@ static GntWs gnt_ws_layout(int R, int S, int V, int depth) {
   size_t o = 0;
   w.emb = o, o += align_up(N * GPN_EMB_HALF * f);
   w.emb_ray = o, o += align_up((size_t)R * GPN_EMB_HALF * f);
-  w.feat = o, o += align_up(N * V * C64 * f);
+  w.feat = o, o += align_up(((N + 15) / 16 * 16) * V * C64 * f);  // (whole tiles: the fused path writes tile-major)
   w.q = o, o += align_up(N * C64 * f);
   w.hidden = o, o += align_up(N * V * depth * 8 * f);    // [N,V,depth,8]
   w.stats = o, o += align_up(N * depth * C64 * f);        // [N,depth,64]
@@ -2725,20 +2778,27 @@ static int gnt_forward_impl(const gpn_gnt_weights_t* W, const gpn_project_args_t
   float* pre = reinterpret_cast<float*>(ws + L.pre);
   int32_t* perm = reinterpret_cast<int32_t*>(ws + L.perm);
   int rc;
+  gpn_project_args_t pa_;
   if (proj) {
-    gpn_project_args_t pa = *proj;
+    gpn_project_args_t& pa = pa_;
+    pa = *proj;
     pa.xyz = pts, pa.N = (int)N;
     // (pa.ray_diff stays null unless the caller wants the [N,V,4] array: k_rd_pack computes its own)
     if (!pa.mask) pa.mask = reinterpret_cast<float*>(ws + L.mask);
     GPN_REQUIRE(pa.V == V && pa.feat_c == W->in_feat_ch, "gpn_render_pass: proj.V / proj.feat_c do not match");
-    if ((rc = gpn_project_rgbfeat(&pa, &W->rgbfeat0, &W->rgbfeat2, feat, q, prec, stream))) return rc;
+    // masks -> visibility order -> the fused kernel walks the points in that order and writes the
+    // feature rows and ray_diff of every (tile, view) pair as the contiguous blocks k_view_attn reads
+    if ((rc = proj_mask_launch(&pa, stream))) return rc;
     mask = pa.mask;
   }
   if ((rc = gpn_vis_order(mask, (int)N, V, perm, ws + L.vis_scratch, stream))) return rc;
   float* rdp = reinterpret_cast<float*>(ws + L.rdiff);
-  if ((rc = rd_pack_launch(proj ? nullptr : ray_diff, pts, proj ? proj->qry_pos : nullptr,
-                           proj ? proj->src_pos : nullptr, perm, (int)N, V, rdp, stream)))
+  if (proj) {
+    if ((rc = proj_rgbfeat_launch(&pa_, &W->rgbfeat0, &W->rgbfeat2, feat, q, perm, rdp, 1, prec, stream))) return rc;
+  } else if ((rc = rd_pack_launch(ray_diff, nullptr, nullptr, nullptr, perm, (int)N, V, rdp, stream))) {
     return rc;
+  }
+  const int va_layout = proj ? 3 : 1;
   if ((rc = gpn_posenc(pts, ray_d, R, S, emb, emb_ray, stream))) return rc;
   // (mask given: the feature rows of masked pairs, which gpn_view_attn never uses, are not stored)
   if (!proj &&
@@ -2752,7 +2812,7 @@ static int gnt_forward_impl(const gpn_gnt_weights_t* W, const gpn_project_args_t
     float* ab = sem ? reinterpret_cast<float*>(ws + L.abar) + l * 4 : nullptr;
     const gpn_view_layer_t* vl = &W->view[l];
     const gpn_ray_layer_t* rl = &W->ray[l];
-    if ((rc = view_attn_launch(vl, q, feat, rdp, 1, mask, perm, (int)N, V, q, hd, D * 8, st, D * C64, prec, stream)))
+    if ((rc = view_attn_launch(vl, q, feat, rdp, va_layout, mask, perm, (int)N, V, q, hd, D * 8, st, D * C64, prec, stream)))
       return rc;
     if ((rc = gpn_ff(vl->ff_norm_w, vl->ff_norm_b, &vl->ff1, &vl->ff2, q, (int)N, q, prec, stream))) return rc;
     if (l % 2 == 0)

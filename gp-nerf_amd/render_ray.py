@@ -47,13 +47,27 @@ def sample_along_camera_ray(ray_o, ray_d, depth_range, N_samples, inv_uniform=Fa
     return pts, z
 
 
+_det_u_cache = {}
+
+
+def _det_u(n, dev):
+    """The deterministic quantiles of the inverse-CDF lookup: the reference's host formula
+    (torch.linspace on the CPU, render_ray.py:36), copied to the device ONCE per (n, device) -- a
+    pageable host-to-device copy per call would make the host wait for the whole coarse pass."""
+    key = (int(n), str(dev))
+    u = _det_u_cache.get(key)
+    if u is None:
+        u = _det_u_cache[key] = torch.linspace(0.0, 1.0, n).to(dev)
+    return u
+
+
 def _fine(ray_o, ray_d, weights, z_vals, N_importance, det, inv_uniform):
     ray_o, ray_d = _f(ray_o, "ray_o"), _f(ray_d, "ray_d")
     weights, z_vals = _f(weights, "weights"), _f(z_vals, "z_vals")
     R, S = z_vals.shape
     dev = z_vals.device
     if det:
-        u = torch.linspace(0.0, 1.0, N_importance).to(dev)  # same host formula as the reference
+        u = _det_u(N_importance, dev)
         stride = 0
     else:
         u = torch.rand((R, N_importance), device=dev)
@@ -81,7 +95,7 @@ def sample_pdf(bins, weights, N_samples, det=False):
     R, M = weights.shape
     dev = bins.device
     if det:
-        u, stride = torch.linspace(0.0, 1.0, N_samples).to(dev), 0
+        u, stride = _det_u(N_samples, dev), 0
     else:
         u, stride = torch.rand((R, N_samples), device=dev), N_samples
     out = torch.empty((R, N_samples), device=dev)

@@ -126,8 +126,8 @@ class GNT(nn.Module):
         self._wcache = None
         self._ws = None
         # 'bf16x3' (default): split-bf16 MFMA with fp32 accumulation, ~5e-6 of the tensor scale end to
-        # end against the reference's golden vectors (bar: 1e-4), 1.45x the rays/s of 'fp32'.
-        # 'fp32': exact fp32 MFMA in the reference's operation order.  See include/gpnerf_hip.h.
+        # end against the reference's golden vectors (bar: 1e-4), 1.7x the rays/s of 'fp32'.
+        # 'fp32': exact fp32 MFMA (the arithmetic bench.py reports as its headline).  See include/gpnerf_hip.h.
         self.precision = "bf16x3"
 
     # ------------------------------------------------------------------ weights -> C struct
@@ -177,10 +177,16 @@ class GNT(nn.Module):
         return W
 
     def _workspace(self, R, S, V, dev):
+        """One workspace per (device, stream): two streams driving this module do not share scratch
+        memory (calls on ONE stream are ordered by the stream itself)."""
         need = _lib.lib().gpn_gnt_workspace_bytes(R, S, V, self.trans_depth)
-        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
-        return self._ws, need
+        if self._ws is None:
+            self._ws = {}
+        key = (dev.index, int(torch.cuda.current_stream().cuda_stream))
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+        return ws, need
 
     # ------------------------------------------------------------------ kernels
     def run(self, rgb_feat, ray_diff, mask, pts, ray_d, z_vals=None, deep_dense=None, deep_map=None,

@@ -710,6 +710,33 @@ def test_gnt_forward_vs_golden(dev, net, prec, golden, S):
     assert torch.equal(out2, out[:5]) and torch.equal(sem2, sem[:5]), "results depend on batch size"
 
 
+def test_two_streams_have_their_own_workspace(dev, net):
+    """One GNT module driven from two HIP streams at once (the workspace used to be one
+    per module): the forwards are enqueued alternately on two streams with different inputs and every
+    result must equal the one the default stream gives alone."""
+    cd = to(dev, cases.g2_gnt(48))
+    net.precision = "bf16x3"
+
+    def fwd(lo, hi):
+        return net(cd["rgb_feat"][lo:hi], cd["deep_sem"][lo:hi], cd["ray_diff"][lo:hi], cd["mask"][lo:hi],
+                   cd["pts"][lo:hi], cd["ray_d"][lo:hi])
+    R = cd["pts"].shape[0]
+    h = R // 2
+    want = [fwd(0, h), fwd(h, R)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    got = [None, None]
+    for rep in range(3):  # several rounds in flight on both streams
+        for k, (lo, hi) in enumerate(((0, h), (h, R))):
+            with torch.cuda.stream(streams[k]):
+                got[k] = fwd(lo, hi)
+    torch.cuda.synchronize()
+    assert len(net._ws) >= 3  # default stream + the two side streams
+    for k in range(2):
+        assert torch.equal(got[k][0], want[k][0]) and torch.equal(got[k][1], want[k][1]), k
+    net.precision = "fp32"
+
+
 # ------------------------------------------------------------------------------ render_rays / image
 def _model(net):
     return types.SimpleNamespace(net_coarse=net, net_fine=None)

@@ -8,6 +8,8 @@ rgb / depth / semantic tiles are all-gathered with RCCL (`torch.distributed`, ba
 """
 from collections import OrderedDict
 
+import os
+
 import torch
 
 from .render_ray import render_rays
@@ -235,6 +237,9 @@ def render_image_sharded(ray_sampler, ray_batch, model, projector, chunk_size, N
     multi = dist.is_initialized()
     G = dist.get_world_size(group) if multi else 1
     rank = dist.get_rank(group) if multi else 0
+    # the collectives are issued in a one-rank job too when asked for (tests: the RCCL calls of this
+    # function run on real hardware with a single GPU)
+    coll = G > 1 or (multi and os.environ.get("GPN_SHARD_FORCE_COLLECTIVES") == "1")
     root = dist.get_global_rank(group, 0) if (multi and group is not None) else 0
     if labels_only and sem_head is None:
         raise ValueError("labels_only=True needs a sem_head")
@@ -250,7 +255,7 @@ def render_image_sharded(ray_sampler, ray_batch, model, projector, chunk_size, N
             out[lvl] = None
             continue
         tile = tiles[lvl]["shared"]
-        if G > 1:
+        if coll:
             full = torch.empty((G * tile.shape[0], tile.shape[1]), device=dev)
             dist.all_gather_into_tensor(full, tile, group=group)
         else:
@@ -258,7 +263,7 @@ def render_image_sharded(ray_sampler, ray_batch, model, projector, chunk_size, N
         out[lvl] = merge_rank_tiles(tiles[lvl]["shared_cols"], full, Hs, Ws)
         ftile = tiles[lvl]["feats"]
         if ftile is not None:  # labels_only: the feature tiles go to rank 0 only
-            if G > 1:
+            if coll:
                 bufs = [torch.empty_like(ftile) for _ in range(G)] if rank == 0 else None
                 dist.gather(ftile, bufs, dst=root, group=group)
                 if rank == 0:
@@ -272,7 +277,7 @@ def render_image_sharded(ray_sampler, ray_batch, model, projector, chunk_size, N
                 if render_stride == 1:  # reference eval_gpnerf.py:201-203: the head works on the half grid
                     feats = feats[::2, ::2, :]
                 lab = sem_head.labels(feats.permute(2, 0, 1).unsqueeze(0).contiguous(), torch.uint8)
-            if labels_only and G > 1:
+            if labels_only and coll:
                 hh, ww = (len(range(0, Hs, 2)), len(range(0, Ws, 2))) if render_stride == 1 else (Hs, Ws)
                 if lab is None:
                     lab = torch.empty((2 * hh, 2 * ww), dtype=torch.uint8, device=dev)

@@ -258,7 +258,16 @@ def main():
         faulthandler.dump_traceback_later(150, exit=True)  # a hang names its line
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # development aid: GPN_BENCH_FORCE_DIST=1 runs the N>1 code path (RCCL process group, barrier,
+    # all-reduce of the step time, all-gather of the tiles inside the timed steps) in a ONE-rank job, so that
+    # those calls can be exercised on a one-GPU box.  Never set by the driver.
+    multi = world > 1 or os.environ.get("GPN_BENCH_FORCE_DIST") == "1"
+    if multi:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if rehearse:
             dist.init_process_group("gloo")
         else:
@@ -271,14 +280,14 @@ def main():
     model = types.SimpleNamespace(net_coarse=net, net_fine=None)
     rb = ray_chunk(scene, rank, world, dev)
     tile_w = 2 * (3 + 1 + 512)
-    gathered = torch.empty((world * CHUNK, tile_w), device=dev) if world > 1 else None
+    gathered = torch.empty((world * CHUNK, tile_w), device=dev) if multi else None
 
     def make_step(sc, batch, n_samples, n_importance):
         def step(collective=True):
             ret = render_rays(batch, model, sc.featmaps, sc.deep, projector, N_samples=n_samples,
                               inv_uniform=True, N_importance=n_importance, det=True, ret_alpha=True,
                               single_net=True)
-            if world > 1 and collective:  # rgb / depth / semantic tiles of both levels, one collective
+            if multi and collective:  # rgb / depth / semantic tiles of both levels, one collective
                 c, f = ret["outputs_coarse"], ret["outputs_fine"] or ret["outputs_coarse"]
                 tile = torch.cat([c["rgb"], c["depth"][:, None], c["feats_out"],
                                   f["rgb"], f["depth"][:, None], f["feats_out"]], dim=1)
@@ -293,7 +302,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -315,7 +324,7 @@ def main():
                 r = step()
             fence()
             dt = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -508,7 +517,7 @@ def main():
             omode: other, "stage_ms_one_step": stages, "legs": legs, "full_image": full_image,
         }
         print(json.dumps(line))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -1654,6 +1654,9 @@ k_qpos(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ q_in,
 }
 
 // ------------------------------------------------------------------------------------ ray attention
+#ifndef GPN_RAY1
+#define GPN_RAY1 1  // S <= 64: k_ray1 (one wave per ray, keys / values in registers); 0: k_ray_attn for every S
+#endif
 // One wave per 16-sample tile of a ray; RPW rays per workgroup share the weights.
 // LDS: Wq Wk Wv Wo [64][68] | bO gamma beta [64] | Ks [RPW][S][68] | Vt [RPW][64][S+4]
 //      | part [RPW][NT][4][S]   (per-wave column sums of A, reduced in fixed order)
@@ -1958,6 +1961,230 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
   }
   RA_MARK(4);
   RA_END();
+}
+
+// ---- k_ray1: ONE wave per ray (NT <= 4, i.e. S <= 64).  The keys and values of a ray never leave the
+// wave that made them: the T-tile a k projection produces IS the A operand of the score MFMAs of that
+// key tile (lane (j, g) holds K[key j][channel 16h + 4g + r]) and a v projection in normal orientation
+// (lin_N) IS the A operand of the P.V MFMAs, so K and V stay in 2 x 16 NT registers instead of going
+// through LDS, and no barrier is left in the kernel: the waves of a workgroup share nothing but the
+// weight images.  Same arithmetic in the same order as k_ray_attn (bit-identical results).
+constexpr int ray1_lds_floats(bool spl) { return 4 * wimg_floats(spl, 64, 4, LDW) + 3 * 64; }
+#define RAY1_WAVES 8
+
+template <int NT, bool SPL>
+__global__ void __launch_bounds__(RAY1_WAVES * 64, 2)
+k_ray1(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S, float* __restrict__ x_out,
+       float* __restrict__ abar, int abar_ld, float* __restrict__ weights) {
+  constexpr int NTHR = RAY1_WAVES * 64;
+  float* Wq = smem;
+  float* Wk = Wq + wimg_floats(SPL, 64, 4, LDW);
+  float* Wv = Wk + wimg_floats(SPL, 64, 4, LDW);
+  float* Wo = Wv + wimg_floats(SPL, 64, 4, LDW);
+  float* bO = Wo + wimg_floats(SPL, 64, 4, LDW);
+  float* gam = bO + 64;
+  float* bet = gam + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int jrev = (int)(__builtin_bitreverse32((unsigned)j) >> 28);
+  {  // two-phase staging (gnt_mfma.h): every global load first, then the LDS images
+    WStage<SPL, 64, 4, NTHR> sq, sk, sv, so;
+    VecStage<64, NTHR> vo, vg, vb;
+    sq.load(Lw.q.w, 64, 64, tid), sk.load(Lw.k.w, 64, 64, tid), sv.load(Lw.v.w, 64, 64, tid);
+    so.load(Lw.out.w, 64, 64, tid);
+    vo.load(Lw.out.b, 64, tid), vg.load(Lw.attn_norm_w, 64, tid), vb.load(Lw.attn_norm_b, 64, tid);
+    sq.store(Wq, LDW, tid), sk.store(Wk, LDW, tid), sv.store(Wv, LDW, tid), so.store(Wo, LDW, tid);
+    vo.store(bO, tid), vg.store(gam, tid), vb.store(bet, tid);
+  }
+  __syncthreads();
+  const float qscale = 0.25f * 1.44269504088896341f;  // 1/sqrt(16) and log2(e): the softmax is a bare 2^x
+  for (int ray = blockIdx.x * RAY1_WAVES + wave; ray < R; ray += (int)gridDim.x * RAY1_WAVES) {
+    const size_t rbase = (size_t)ray * S;
+    // ---- keys and values of the whole ray, tile by tile, into registers
+    typedef typename std::conditional<SPL, bf8, f4>::type kv_t;
+    kv_t kk[NT][4], vv[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int sq_ = 16 * t + j, sc = sq_ < S ? sq_ : S - 1;
+      f4 x[4], xn[4];
+#pragma unroll
+      for (int T = 0; T < 4; ++T) x[T] = ld4(x_in + (rbase + sc) * C64 + 16 * T + 4 * g);
+      layernorm_T(x, xn, gam, bet, 1e-6f, lane);
+      f4 kT[4], vN[4];
+#pragma unroll
+      for (int M = 0; M < 4; ++M) kT[M] = f4_zero(), vN[M] = f4_zero();
+      if constexpr (SPL) {
+        XS xs[2] = {split8(xn[0], xn[1]), split8(xn[2], xn[3])};
+        lin_Sx<4, 4>(Wk, xs, kT, lane);
+        lin_Sx<4, 4, false>(Wv, xs, vN, lane);
+#pragma unroll
+        for (int M = 0; M < 4; ++M) kk[t][M] = split4(kT[M]), vv[t][M] = split4(vN[M]);
+      } else {
+        lin_T<4, 4>(Wk, LDW, xn, kT, lane);
+        lin_N<4, 4>(Wv, LDW, xn, vN, lane);
+#pragma unroll
+        for (int M = 0; M < 4; ++M) kk[t][M] = kT[M], vv[t][M] = vN[M];
+      }
+    }
+    // ---- queries, tile by tile
+    float csum[4][(NT + 3) / 4];  // column sums of the attention tiles over all queries (abar), per head
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+      for (int q = 0; q < (NT + 3) / 4; ++q) csum[h][q] = 0.0f;
+#pragma unroll 1
+    for (int t = 0; t < NT; ++t) {
+      const int sq_ = 16 * t + j;
+      const bool qvalid = sq_ < S;
+      const int sc = qvalid ? sq_ : S - 1;
+      const float qsel = qvalid ? 1.0f : 0.0f;
+      f4 x[4], xn[4], qT[4];
+#pragma unroll
+      for (int T = 0; T < 4; ++T) x[T] = ld4(x_in + (rbase + sc) * C64 + 16 * T + 4 * g);
+      layernorm_T(x, xn, gam, bet, 1e-6f, lane);
+#pragma unroll
+      for (int M = 0; M < 4; ++M) qT[M] = f4_zero();
+      if constexpr (SPL) {
+        XS xs[2] = {split8(xn[0], xn[1]), split8(xn[2], xn[3])};
+        lin_Sx<4, 4>(Wq, xs, qT, lane);
+      } else {
+        lin_T<4, 4>(Wq, LDW, xn, qT, lane);
+      }
+#pragma unroll
+      for (int M = 0; M < 4; ++M) qT[M] = qT[M] * f4_splat(qscale);
+      const bool all_q = __all(qvalid);
+      f4 oT[4], wacc[NT];
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) wacc[kt] = f4_zero();
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        f4 sT[NT];
+        auto scores = [&]() {
+          if constexpr (SPL) {
+            const bf8 qs = split4(qT[h]);
+            bf8 qb1, qb2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              qb1[e] = qs[e], qb1[4 + e] = qs[e];
+              qb2[e] = qs[4 + e], qb2[4 + e] = (__bf16)0.0f;
+            }
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) sT[kt] = mfma_bf(kk[kt][h], qb2, f4_zero());
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) sT[kt] = mfma_bf(kk[kt][h], qb1, sT[kt]);
+          } else {
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) sT[kt] = f4_zero();
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int kt = 0; kt < NT; ++kt) sT[kt] = mfma16(kk[kt][h][r], qT[h][r], sT[kt]);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (16 * (NT - 1) + 4 * g + r >= S) sT[NT - 1][r] = -INFINITY;
+        };
+        scores();
+        float tot;
+        {
+          float sum = 0.f;
+#pragma unroll
+          for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sT[kt][r] = __builtin_amdgcn_exp2f(sT[kt][r]);
+            sum += (sT[kt].x + sT[kt].y) + (sT[kt].z + sT[kt].w);
+          }
+          tot = sum_over_g(sum);
+          if (__builtin_expect(__any(!(tot > 1e-30f && tot < 1e30f)), 0)) {  // shifted form (see k_ray_attn)
+            scores();
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) mx = max3_nc(mx, max_nc(sT[kt].x, sT[kt].y), max_nc(sT[kt].z, sT[kt].w));
+            mx = max_over_g(mx);
+            sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) sT[kt][r] = __builtin_amdgcn_exp2f(sT[kt][r] - mx);
+              sum += (sT[kt].x + sT[kt].y) + (sT[kt].z + sT[kt].w);
+            }
+            tot = sum_over_g(sum);
+          }
+        }
+        const float inv = __builtin_amdgcn_rcpf(tot);
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) sT[kt] = sT[kt] * f4_splat(inv);
+        if (!all_q) {
+#pragma unroll
+          for (int kt = 0; kt < NT; ++kt) sT[kt] = sT[kt] * f4_splat(qsel);
+        }
+        if (t == 0) {
+#pragma unroll
+          for (int kt = 0; kt < NT; ++kt) wacc[kt] = wacc[kt] + sT[kt];
+        }
+        if (abar != nullptr) {
+#pragma unroll
+          for (int grp = 0; grp < (NT + 3) / 4; ++grp) {
+            float cv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) cv[e] = 4 * grp + (e >> 2) < NT ? sT[(4 * grp + (e >> 2)) % NT][e & 3] : 0.0f;
+            csum[h][grp] += row_sums16(cv, j);
+          }
+        }
+        f4 o0 = f4_zero(), o1 = f4_zero();
+        if constexpr (SPL) {
+#pragma unroll
+          for (int kt = 0; kt < NT; ++kt) {
+            const bf8 ps = split4(sT[kt]);
+            bf8 pb1, pb2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              pb1[e] = ps[e], pb1[4 + e] = ps[e];
+              pb2[e] = ps[4 + e], pb2[4 + e] = (__bf16)0.0f;
+            }
+            if ((kt & 1) == 0) o0 = mfma_bf(vv[kt][h], pb1, mfma_bf(vv[kt][h], pb2, o0));
+            else o1 = mfma_bf(vv[kt][h], pb1, mfma_bf(vv[kt][h], pb2, o1));
+          }
+        } else {
+#pragma unroll
+          for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if ((kt & 1) == 0) o0 = mfma16(vv[kt][h][r], sT[kt][r], o0);
+              else o1 = mfma16(vv[kt][h][r], sT[kt][r], o1);
+            }
+          }
+        }
+        oT[h] = o0 + o1;
+      }
+      f4 y[4];
+#pragma unroll
+      for (int M = 0; M < 4; ++M) y[M] = ld4(bO + 16 * M + 4 * g);
+      lin<SPL, 4, 4>(Wo, LDW, oT, y, lane);
+      if (qvalid) {
+#pragma unroll
+        for (int M = 0; M < 4; ++M) st4(x_out + (rbase + sq_) * C64 + 16 * M + 4 * g, y[M] + x[M]);
+      }
+      if (weights != nullptr && t == 0 && j == 0) {  // head-mean of attention row 0 (:216)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = 16 * kt + 4 * g + r;
+            if (key < S) weights[rbase + key] = wacc[kt][r] * 0.25f;
+          }
+      }
+    }
+    if (abar != nullptr) {  // lane j holds the column total of value bitrev4(j) of its 16-value group
+#pragma unroll
+      for (int h = 0; h < 4; ++h)
+#pragma unroll
+        for (int grp = 0; grp < (NT + 3) / 4; ++grp) {
+          const int kt = 4 * grp + (jrev >> 2), key = 16 * kt + 4 * g + (jrev & 3);
+          if (kt < NT && key < S) abar[(rbase + key) * abar_ld + h] = csum[h][grp] / (float)S;
+        }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------ semantic aggregation
@@ -2596,6 +2823,19 @@ extern "C" int gpn_qpos(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const 
 template <int NT, bool SPL>
 static int launch_ray_attn_p(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,
                              float* abar, int abar_ld, float* weights, hipStream_t stream) {
+#if GPN_RAY1
+  if constexpr (NT <= 4) {  // one wave per ray, keys / values in registers (k_ray1)
+    const size_t lds1 = sizeof(float) * ray1_lds_floats(SPL);
+    int rc1 = set_lds_limit(reinterpret_cast<const void*>(k_ray1<NT, SPL>), lds1);
+    if (rc1) return rc1;
+    const int grid1 = persistent_grid(((long long)R + RAY1_WAVES - 1) / RAY1_WAVES);
+    GpnStageTimer timer_k_ray1_(GPN_ST_RAY_ATTN, stream);
+    hipLaunchKernelGGL((k_ray1<NT, SPL>), dim3(grid1), dim3(RAY1_WAVES * 64), lds1, stream, *L, x_in, R, S, x_out,
+                       abar, abar_ld, weights);
+    GPN_LAUNCH_CHECK("k_ray1");
+    return GPN_OK;
+  }
+#endif
   using Cfg = RayCfg<NT>;
   const size_t lds = sizeof(float) * Cfg::LDS_FLOATS;
   int rc = set_lds_limit(reinterpret_cast<const void*>(k_ray_attn<NT, SPL>), lds);

@@ -1655,7 +1655,7 @@ k_qpos(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ q_in,
 
 // ------------------------------------------------------------------------------------ ray attention
 #ifndef GPN_RAY1
-#define GPN_RAY1 1  // S <= 64: k_ray1 (one wave per ray, keys / values in registers); 0: k_ray_attn for every S
+#define GPN_RAY1 1  // S <= 48: k_ray1 (one wave per ray, keys / values in registers); 0: k_ray_attn for every S
 #endif
 // One wave per 16-sample tile of a ray; RPW rays per workgroup share the weights.
 // LDS: Wq Wk Wv Wo [64][68] | bO gamma beta [64] | Ks [RPW][S][68] | Vt [RPW][64][S+4]
@@ -1963,14 +1963,15 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
   RA_END();
 }
 
-// ---- k_ray1: ONE wave per ray (NT <= 4, i.e. S <= 64).  The keys and values of a ray never leave the
+// ---- k_ray1: ONE wave per ray (instantiated for NT <= 4, used for NT <= 3, i.e. S <= 48).  The keys and values of a ray never leave the
 // wave that made them: the T-tile a k projection produces IS the A operand of the score MFMAs of that
 // key tile (lane (j, g) holds K[key j][channel 16h + 4g + r]) and a v projection in normal orientation
 // (lin_N) IS the A operand of the P.V MFMAs, so K and V stay in 2 x 16 NT registers instead of going
 // through LDS, and no barrier is left in the kernel: the waves of a workgroup share nothing but the
 // weight images.  Same arithmetic in the same order as k_ray_attn (bit-identical results).
-constexpr int ray1_lds_floats(bool spl) { return 4 * wimg_floats(spl, 64, 4, LDW) + 3 * 64; }
 #define RAY1_WAVES 8
+// weight images | bO gamma beta | per wave: the attention row of query 0 of every head (for `weights`)
+constexpr int ray1_lds_floats(bool spl) { return 4 * wimg_floats(spl, 64, 4, LDW) + 3 * 64 + RAY1_WAVES * 4 * 64; }
 
 template <int NT, bool SPL>
 __global__ void __launch_bounds__(RAY1_WAVES * 64, 2)
@@ -1985,6 +1986,7 @@ k_ray1(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S, float* 
   float* gam = bO + 64;
   float* bet = gam + 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* wrow = bet + 64 + wave * 256;  // [4 heads][64 keys]: query 0's attention row (lanes j == 0 only)
   const int j = lane & 15, g = lane >> 4;
   const int jrev = (int)(__builtin_bitreverse32((unsigned)j) >> 28);
   {  // two-phase staging (gnt_mfma.h): every global load first, then the LDS images
@@ -2053,9 +2055,7 @@ k_ray1(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S, float* 
 #pragma unroll
       for (int M = 0; M < 4; ++M) qT[M] = qT[M] * f4_splat(qscale);
       const bool all_q = __all(qvalid);
-      f4 oT[4], wacc[NT];
-#pragma unroll
-      for (int kt = 0; kt < NT; ++kt) wacc[kt] = f4_zero();
+      f4 oT[4];
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
         f4 sT[NT];
@@ -2118,9 +2118,9 @@ k_ray1(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S, float* 
 #pragma unroll
           for (int kt = 0; kt < NT; ++kt) sT[kt] = sT[kt] * f4_splat(qsel);
         }
-        if (t == 0) {
+        if (weights != nullptr && t == 0 && j == 0) {  // (parked in LDS: 16 registers less through the head loop)
 #pragma unroll
-          for (int kt = 0; kt < NT; ++kt) wacc[kt] = wacc[kt] + sT[kt];
+          for (int kt = 0; kt < NT; ++kt) st4(wrow + h * 64 + 16 * kt + 4 * g, sT[kt]);
         }
         if (abar != nullptr) {
 #pragma unroll
@@ -2157,22 +2157,29 @@ k_ray1(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S, float* 
         }
         oT[h] = o0 + o1;
       }
-      f4 y[4];
+      // the residual input is read AGAIN here (L2-hot) instead of being held through the attention: 16
+      // registers that the NT = 4 instantiation does not have
+      f4 y[4], xr[4];
+#pragma unroll
+      for (int T = 0; T < 4; ++T) xr[T] = ld4(x_in + (rbase + sc) * C64 + 16 * T + 4 * g);
 #pragma unroll
       for (int M = 0; M < 4; ++M) y[M] = ld4(bO + 16 * M + 4 * g);
       lin<SPL, 4, 4>(Wo, LDW, oT, y, lane);
       if (qvalid) {
 #pragma unroll
-        for (int M = 0; M < 4; ++M) st4(x_out + (rbase + sq_) * C64 + 16 * M + 4 * g, y[M] + x[M]);
+        for (int M = 0; M < 4; ++M) st4(x_out + (rbase + sq_) * C64 + 16 * M + 4 * g, y[M] + xr[M]);
       }
       if (weights != nullptr && t == 0 && j == 0) {  // head-mean of attention row 0 (:216)
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
+        for (int kt = 0; kt < NT; ++kt) {
+          const float* wr = wrow + 16 * kt + 4 * g;
+          const f4 w4 = ((ld4(wr) + ld4(wr + 64)) + ld4(wr + 128)) + ld4(wr + 192);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int key = 16 * kt + 4 * g + r;
-            if (key < S) weights[rbase + key] = wacc[kt][r] * 0.25f;
+            if (key < S) weights[rbase + key] = w4[r] * 0.25f;
           }
+        }
       }
     }
     if (abar != nullptr) {  // lane j holds the column total of value bitrev4(j) of its 16-value group
@@ -2824,7 +2831,10 @@ template <int NT, bool SPL>
 static int launch_ray_attn_p(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,
                              float* abar, int abar_ld, float* weights, hipStream_t stream) {
 #if GPN_RAY1
-  if constexpr (NT <= 4) {  // one wave per ray, keys / values in registers (k_ray1)
+  // one wave per ray, keys / values in registers (k_ray1).  Per launch at R = 4096 (rocprofv3): S = 48 fp32
+  // 111 -> 89 us, bf16x3 59 -> 52.5 us; S = 64 (the 128 key / value registers leave the compiler no room)
+  // fp32 124.5 -> 125, bf16x3 68.5 -> 72 us: k_ray_attn stays the kernel of S > 48
+  if constexpr (NT <= 3) {
     const size_t lds1 = sizeof(float) * ray1_lds_floats(SPL);
     int rc1 = set_lds_limit(reinterpret_cast<const void*>(k_ray1<NT, SPL>), lds1);
     if (rc1) return rc1;

@@ -1969,12 +1969,20 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
 // (lin_N) IS the A operand of the P.V MFMAs, so K and V stay in 2 x 16 NT registers instead of going
 // through LDS, and no barrier is left in the kernel: the waves of a workgroup share nothing but the
 // weight images.  Same arithmetic in the same order as k_ray_attn (bit-identical results).
+#ifndef RAY1_WAVES
 #define RAY1_WAVES 8
+#endif
+#ifndef RAY1_MINW
+#define RAY1_MINW 2
+#endif
+#ifndef RAY1_MAXNT
+#define RAY1_MAXNT 3
+#endif
 // weight images | bO gamma beta | per wave: the attention row of query 0 of every head (for `weights`)
 constexpr int ray1_lds_floats(bool spl) { return 4 * wimg_floats(spl, 64, 4, LDW) + 3 * 64 + RAY1_WAVES * 4 * 64; }
 
 template <int NT, bool SPL>
-__global__ void __launch_bounds__(RAY1_WAVES * 64, 2)
+__global__ void __launch_bounds__(RAY1_WAVES * 64, RAY1_MINW)
 k_ray1(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S, float* __restrict__ x_out,
        float* __restrict__ abar, int abar_ld, float* __restrict__ weights) {
   constexpr int NTHR = RAY1_WAVES * 64;
@@ -2834,7 +2842,7 @@ static int launch_ray_attn_p(const gpn_ray_layer_t* L, const float* x_in, int R,
   // one wave per ray, keys / values in registers (k_ray1).  Per launch at R = 4096 (rocprofv3): S = 48 fp32
   // 111 -> 89 us, bf16x3 59 -> 52.5 us; S = 64 (the 128 key / value registers leave the compiler no room)
   // fp32 124.5 -> 125, bf16x3 68.5 -> 72 us: k_ray_attn stays the kernel of S > 48
-  if constexpr (NT <= 3) {
+  if constexpr (NT <= RAY1_MAXNT) {
     const size_t lds1 = sizeof(float) * ray1_lds_floats(SPL);
     int rc1 = set_lds_limit(reinterpret_cast<const void*>(k_ray1<NT, SPL>), lds1);
     if (rc1) return rc1;

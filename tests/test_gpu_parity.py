@@ -544,10 +544,12 @@ def test_posenc_argument_ranges(dev, scale):
     assert err < 2e-7, err
 
 
-def test_ray_attn_large_scores(dev, prec):
-    """gpn_ray_attn takes bare exponentials in bf16x3 mode (no running maximum) and falls back to the
-    shifted softmax when a denominator leaves the safe range.  q_fc / k_fc scaled 17x put the scores at
-    ~+-100 (2^144 overflows fp32), so this case runs the fallback; S = 40 also has padding keys.
+@pytest.mark.parametrize("S", [40, 60])
+def test_ray_attn_large_scores(dev, prec, S):
+    """gpn_ray_attn takes bare exponentials (no running maximum) and falls back to the shifted softmax
+    when a denominator leaves the safe range.  q_fc / k_fc scaled 17x put the scores at ~+-100 (2^144
+    overflows fp32), so this case runs the fallback; both sizes have padding keys.  S = 40 runs k_ray1
+    (one wave per ray, S <= 48), S = 60 k_ray_attn.
     Tolerance: a score of 100 carries 100 * 2^-16 of split-operand error, i.e. ~4e-4 on an attention
     weight (fp32 mode: 100 * 2^-23)."""
     from gp_nerf_amd import _lib
@@ -564,7 +566,7 @@ def test_ray_attn_large_scores(dev, prec):
     W = big._weights()
     L, st = _lib.lib(), _lib.stream()
     pc = _lib.precision_code(prec)
-    R, S = 37, 40
+    R = 37
     x = torch.randn(R, S, 64, generator=torch.Generator().manual_seed(11)) * 1.5
     _, A, mid = oracle.gnt.ray_transformer(sd, "view_selftrans.0", x)
     scores_max = float((torch.log(A.max(dim=-1)[0]) - torch.log(A.min(dim=-1)[0])).max())

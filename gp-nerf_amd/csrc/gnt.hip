@@ -1141,7 +1141,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
           ah = f4_relu_t<SPL>(ah);
           lin<SPL, 1, 4>(L.A2, VA_LD8, &ah, a, lane);
         }
-const bool vis_v = MODE == VM_HOMOG || ((vis >> v) & 1u) != 0;
+        const bool vis_v = MODE == VM_HOMOG || ((vis >> v) & 1u) != 0;
         // side output for the semantic pass: the 8 hidden values (lanes g < 2), from which
         // gpn_sem_aggregate rebuilds the 64 logits; masked pairs are never read back
         if (hidden != nullptr && lane_ok && vis_v && g < 2)

@@ -91,7 +91,15 @@ __device__ unsigned long long g_ra_phase[16][8];
 extern "C" int gpn_debug_ra_phase(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ra_phase), sizeof(g_ra_phase)) == hipSuccess ? 0 : 1;
 }
+#define VA_T0() unsigned va_t_ = (unsigned)__builtin_readcyclecounter(); unsigned va_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define VA_MARK(k) do { const unsigned n_ = (unsigned)__builtin_readcyclecounter(); va_acc_[k] += n_ - va_t_; va_t_ = n_; } while (0)
+#define VA_COUNT(k) do { va_acc_[k] += 1; } while (0)
+#define VA_END() do { if (blockIdx.x == 3 && lane == 0 && wave < 16) { for (int k_ = 0; k_ < 8; ++k_) g_ra_phase[wave][k_] = va_acc_[k_]; } } while (0)
 #else
+#define VA_T0() do { } while (0)
+#define VA_MARK(k) do { } while (0)
+#define VA_COUNT(k) do { } while (0)
+#define VA_END() do { } while (0)
 #define RA_T0() do { } while (0)
 #define RA_MARK(k) do { } while (0)
 #define RA_END() do { } while (0)
@@ -997,7 +1005,10 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
   };
   f2 l2e = (f2){LOG2E_F, LOG2E_F};
   asm volatile("" : "+v"(l2e));  // keep log2(e) in registers: a literal operand blocks v_pk_fma_f32
+  VA_T0();
   for (;;) {
+    VA_MARK(5);
+    VA_COUNT(7);
     const bool valid = tile * 16 + j < N;
     const bool has_next = tile + tstride < ntiles;  // wave-uniform
     // points of the tile three ahead (consumed when it has become the tile two ahead)
@@ -1063,6 +1074,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
     auto view_loop = [&](auto mode_tag) {
       constexpr int MODE = decltype(mode_tag)::value;
       while (live) {
+        if (MODE == VM_HOMOG) { VA_MARK(4); VA_COUNT(6); }
         const int v = __builtin_ctz(live);
         live &= live - 1;
         // This pair's slot was filled by a DMA issued two iterations ago.  Younger vector-memory
@@ -1075,6 +1087,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
         f4 fcur[4];
         float rd;
         read_slot(par, fcur, rd);
+        if (MODE == VM_HOMOG) VA_MARK(1);
         {  // refill the slot with the pair after next (or, past the end, any valid pair: fixed op count)
           int t2, v2;
           pair_plus2(live, t2, v2);
@@ -1082,6 +1095,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
           dma_pair(nn, tile + (t2 > 0 ? t2 : 0) * tstride, t2 < 0 ? v : v2, par);
           par ^= 1u;
         }
+        if (MODE == VM_HOMOG) VA_MARK(2);
         f4 vp[4], a[4];  // vp = v + pos (the value that is attended over)
 #pragma unroll
         for (int M = 0; M < 4; ++M) {
@@ -1141,6 +1155,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
           ah = f4_relu_t<SPL>(ah);
           lin<SPL, 1, 4>(L.A2, VA_LD8, &ah, a, lane);
         }
+        if (MODE == VM_HOMOG) VA_MARK(3);
         const bool vis_v = MODE == VM_HOMOG || ((vis >> v) & 1u) != 0;
         // side output for the semantic pass: the 8 hidden values (lanes g < 2), from which
         // gpn_sem_aggregate rebuilds the 64 logits; masked pairs are never read back
@@ -1199,6 +1214,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
       }
     };
     STAMP(4);
+    VA_MARK(0);
     bool store_ok = valid;
     unsigned long long redo_next = 0;
     if (online) {
@@ -1268,6 +1284,8 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
     live2 = tile + 2 * tstride < ntiles ? live_of(vis2) : 0u;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last (unused) ring fills land before the wave ends
+  VA_MARK(5);
+  VA_END();
   STAMP(5);
 }
 

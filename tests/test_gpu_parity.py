@@ -712,6 +712,34 @@ def test_gnt_forward_vs_golden(dev, net, prec, golden, S):
     assert torch.equal(out2, out[:5]) and torch.equal(sem2, sem[:5]), "results depend on batch size"
 
 
+@pytest.mark.parametrize("R,S,V", [(1, 1, 1), (2, 7, 2), (5, 33, 1), (3, 17, 16), (2, 128, 3), (2, 9, 32)])
+def test_gnt_forward_edge_shapes(dev, net, prec, R, S, V):
+    """The limits of the C-ABI (GPN_MAX_VIEWS = 32, GPN_MAX_SAMPLES = 128) and the degenerate shapes -- one
+    ray, one sample (a one-key ray attention), one view (a one-term softmax over views), tiles with a
+    single valid point -- through the whole forward against the CPU oracle on the same inputs; some
+    samples have no visible view at all (uniform 1/V attention)."""
+    from gp_nerf_amd import synth
+    seed = 9000 + 131 * R + 17 * S + V
+    rgb_feat = torch.from_numpy(synth.hash_normal(seed, 1, (R, S, V, 35)))
+    deep = torch.from_numpy(synth.hash_normal(seed, 2, (R, S, V, 512)))
+    rd = torch.from_numpy(synth.hash_normal(seed, 3, (R, S, V, 4)))
+    rd[..., :3] = rd[..., :3] / rd[..., :3].norm(dim=-1, keepdim=True)
+    rd[..., 3] = torch.tanh(rd[..., 3])
+    mask = (torch.from_numpy(synth.hash_uniform(seed, 4, (R, S, V, 1))) < 0.6).float()
+    mask[0, 0] = 1.0
+    mask[-1, S // 2] = 0.0
+    ray_d = torch.from_numpy(synth.hash_normal(seed, 5, (R, 3))) * 0.3 + torch.tensor([0.0, 0.0, 1.0])
+    z = 1.0 / torch.linspace(1.0 / 0.1, 1.0 / 10.0, S)
+    pts = (z[None, :, None] * ray_d[:, None]).contiguous()
+    want = oracle.gnt.forward(cases.weights(), rgb_feat, deep, rd, mask, pts, ray_d)
+    cd = to(dev, dict(rgb_feat=rgb_feat, deep=deep, rd=rd, mask=mask, pts=pts, ray_d=ray_d))
+    got = net(cd["rgb_feat"], cd["deep"], cd["rd"], cd["mask"], cd["pts"], cd["ray_d"])
+    errs = {k: rel(g_, w_) for k, g_, w_ in zip(("out", "sem", "sem3d"), got, want)}
+    print("edge shape R=%d S=%d V=%d [%s]: %s" % (R, S, V, prec, errs))
+    assert max(errs.values()) < TOL, errs
+    assert all(bool(torch.isfinite(g_).all()) for g_ in got)
+
+
 def test_two_streams_have_their_own_workspace(dev, net):
     """One GNT module driven from two HIP streams at once (the workspace used to be one
     per module): the forwards are enqueued alternately on two streams with different inputs and every

@@ -42,6 +42,9 @@
 #define VA_SLOT_BYTES (4096 + 256)  // one (tile, view) pair: 16 feature rows + 64 ray_diff floats
 #define VA_DMA_OPS 5
 // cache policy of the feature-row DMA: read once per launch -> non-temporal (measured -5 %)
+#ifndef VA_TILED_DMA
+#define VA_TILED_DMA 1
+#endif
 #ifndef VA_DMA_NT
 #define VA_DMA_NT "nt"
 #endif
@@ -775,7 +778,7 @@ k_rd_pack(const float* __restrict__ rd, const float* __restrict__ xyz, float qx,
   }
 }
 
-template <bool SPL, bool FOLD>
+template <bool SPL, bool FOLD, bool TILED = false>
 __global__ void __launch_bounds__(VA_TPB)
 k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __restrict__ feat,
             const float* __restrict__ ray_diff, const float* __restrict__ mask,
@@ -856,7 +859,34 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
   // 4*half: the rotation makes the read-back below bank-conflict free.
   const int jj8 = lane >> 3, r8 = lane & 7;
   const int cA = (r8 - (jj8 >> 1)) & 7, cB = (r8 - (jj8 >> 1) - 4) & 7;
+  // TILED (layout == 3, the fused path): the 16 rows and the ray_diff run of a pair sit at a wave-uniform
+  // base, so the addresses are a scalar base (scalar unit: free beside the MFMAs) plus per-lane offsets
+  // that never change -- no vector address arithmetic and no cross-lane reads per pair (an fp32 MFMA
+  // kernel pays every vector instruction in full)
+  const unsigned offA = (unsigned)(jj8 * 256 + cA * 16), offB = (unsigned)((8 + jj8) * 256 + cB * 16);
+  const unsigned offR = (unsigned)lane * 4u;
   auto dma_pair = [&](int nn, long long tile_, int vv, unsigned sl) {
+    if constexpr (TILED) {
+      const unsigned tv = (unsigned)__builtin_amdgcn_readfirstlane((int)(tile_ * V + vv));
+      const char* sf = reinterpret_cast<const char*>(feat) + (size_t)tv * (16 * C64 * 4);
+      const char* sr = reinterpret_cast<const char*>(ray_diff) + (size_t)tv * 256;
+      const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane(ring_lds + sl * VA_SLOT_BYTES);
+      const unsigned m0 = base, m1 = base + 1024, m2 = base + 2048 - 128, m3 = base + 3072 - 128, m4 = base + 4096;
+      unsigned keep;
+      asm volatile(
+          "s_waitcnt lgkmcnt(0)\n\t"  // the slot's previous contents have been read into registers
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4 " VA_DMA_NT "\n\t"
+          "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4 " VA_DMA_NT "\n\t"
+          "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4 offset:128 " VA_DMA_NT "\n\t"
+          "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4 offset:128 " VA_DMA_NT "\n\t"
+          "s_mov_b32 m0, %10\n\ts_nop 0\n\tglobal_load_lds_dword %3, %5\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(offA), "v"(offB), "v"(offR), "s"(sf), "s"(sr), "s"(m0), "s"(m1), "s"(m2), "s"(m3), "s"(m4)
+          : "memory");
+      return;
+    }
     const int nA = __shfl(nn, jj8), nB = __shfl(nn, 8 + jj8);
     const size_t rowA = feat_tiled ? ((size_t)tile_ * V + vv) * 16 + jj8 : (size_t)nA * V + vv;
     const size_t rowB = feat_tiled ? ((size_t)tile_ * V + vv) * 16 + 8 + jj8 : (size_t)nB * V + vv;
@@ -2743,17 +2773,26 @@ static int view_attn_launch(const gpn_view_layer_t* L, const float* q_in, const 
   const bool spl = precision == GPN_PREC_BF16X3;
   const bool fold = L->folded != nullptr;
   const size_t lds = sizeof(float) * view_lds_floats(spl) + (VA_TPB / 64) * 2 * VA_SLOT_BYTES;
-  const void* fn = spl ? (fold ? reinterpret_cast<const void*>(k_view_attn<true, true>)
-                               : reinterpret_cast<const void*>(k_view_attn<true, false>))
-                       : (fold ? reinterpret_cast<const void*>(k_view_attn<false, true>)
-                               : reinterpret_cast<const void*>(k_view_attn<false, false>));
+  const bool tiled = VA_TILED_DMA && fold && layout == 3;  // the fused path: scalar-base DMA addressing
+  const void* fn = tiled ? (spl ? reinterpret_cast<const void*>(k_view_attn<true, true, true>)
+                                : reinterpret_cast<const void*>(k_view_attn<false, true, true>))
+                   : spl ? (fold ? reinterpret_cast<const void*>(k_view_attn<true, true>)
+                                 : reinterpret_cast<const void*>(k_view_attn<true, false>))
+                         : (fold ? reinterpret_cast<const void*>(k_view_attn<false, true>)
+                                 : reinterpret_cast<const void*>(k_view_attn<false, false>));
   int rc = set_lds_limit(fn, lds);
   if (rc) return rc;
   const int grid = persistent_grid(((long long)N + (VA_TPB / 4) - 1) / (VA_TPB / 4));
   GpnStageTimer timer_k_view_attn_(GPN_ST_VIEW_ATTN, (hipStream_t)stream);
   const dim3 g3(grid), b3(VA_TPB);
   hipStream_t st = (hipStream_t)stream;
-  if (fold && spl)
+  if (tiled && spl)
+    hipLaunchKernelGGL((k_view_attn<true, true, true>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
+                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, layout);
+  else if (tiled)
+    hipLaunchKernelGGL((k_view_attn<false, true, true>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
+                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, layout);
+  else if (fold && spl)
     hipLaunchKernelGGL((k_view_attn<true, true>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
                        (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, layout);
   else if (fold)

@@ -129,15 +129,45 @@ __device__ __forceinline__ void lin_N(const float* W, int ldw, const f4* x, f4* 
 }
 
 // Sum over the 4 lanes (j, g = 0..3) that share a point.
+#ifndef GPN_SWAP_SUM
+#define GPN_SWAP_SUM 1
+#endif
+// v and its copy with the 16-lane rows (0,1) and (2,3) / the wave halves exchanged, on the vector unit
+// (v_permlane16_swap / v_permlane32_swap of gfx950) instead of a ds_bpermute round trip through LDS.
+// Inline asm: the builtin with two equal inputs is folded into a + a by hipcc (wrong).
+__device__ __forceinline__ void swap16(float v, float& a, float& b) {
+  a = v, b = v;
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap32(float v, float& a, float& b) {
+  a = v, b = v;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
 __device__ __forceinline__ float sum_over_g(float v) {
+#if GPN_SWAP_SUM
+  float a, b;
+  swap16(v, a, b);
+  v = a + b;  // rows 0 / 1: v0 + v1, rows 2 / 3: v2 + v3 (the same two addends as v + shfl_xor(v, 16))
+  swap32(v, a, b);
+  return a + b;
+#else
   v += __shfl_xor(v, 16);
   v += __shfl_xor(v, 32);
   return v;
+#endif
 }
 __device__ __forceinline__ float max_over_g(float v) {
+#if GPN_SWAP_SUM
+  float a, b;
+  swap16(v, a, b);
+  v = max_nc(a, b);
+  swap32(v, a, b);
+  return max_nc(a, b);
+#else
   v = max_nc(v, __shfl_xor(v, 16));
   v = max_nc(v, __shfl_xor(v, 32));
   return v;
+#endif
 }
 
 // Sum over the 16 lanes of a DPP row (lanes with equal l>>4); the total lands in lane 15 of the row.

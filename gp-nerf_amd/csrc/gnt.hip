@@ -824,19 +824,13 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
         const float m = mask[(size_t)sc * V + vc];
         b |= (v < V && m != 0.0f ? 1u : 0u) << (v & 31);
       }
-      b |= __shfl_xor(b, 16);
-      b |= __shfl_xor(b, 32);
-      vis_ = b;
+      vis_ = or_over_g(b);
     }
   };
   // live views of a tile (wave-uniform): visible for some point, or needed by a point that has no
   // visible view at all (its softmax is uniform over all V views)
   auto live_of = [&](unsigned vis_) {
-    unsigned m = vis_ != 0 ? vis_ : all_views;
-    m |= __shfl_xor(m, 1);
-    m |= __shfl_xor(m, 2);
-    m |= __shfl_xor(m, 4);
-    m |= __shfl_xor(m, 8);
+    const unsigned m = or_over_row(vis_ != 0 ? vis_ : all_views);
     return (unsigned)__builtin_amdgcn_readfirstlane(m);
   };
 
@@ -1028,10 +1022,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
   unsigned long long redo_lanes = 0;  // lanes (points) of the current tile to redo in the online form
   // a point = the 4 lanes (j, g = 0..3): all of them redo if any of their channels overflowed
   auto ovf_point = [&](bool o) {
-    unsigned b = o ? 1u : 0u;
-    b |= __shfl_xor(b, 16);
-    b |= __shfl_xor(b, 32);
-    return b != 0;
+    return or_over_g(o ? 1u : 0u) != 0;
   };
   f2 l2e = (f2){LOG2E_F, LOG2E_F};
   asm volatile("" : "+v"(l2e));  // keep log2(e) in registers: a literal operand blocks v_pk_fma_f32

@@ -143,6 +143,25 @@ __device__ __forceinline__ void swap32(float v, float& a, float& b) {
   a = v, b = v;
   asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
+// bitwise OR over the four lanes (j, g = 0..3) of a point / over the 16 lanes of a DPP row
+__device__ __forceinline__ unsigned or_over_g(unsigned v) {
+  float a, b;
+  swap16(__builtin_bit_cast(float, v), a, b);
+  v = __builtin_bit_cast(unsigned, a) | __builtin_bit_cast(unsigned, b);
+  swap32(__builtin_bit_cast(float, v), a, b);
+  return __builtin_bit_cast(unsigned, a) | __builtin_bit_cast(unsigned, b);
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+__device__ __forceinline__ unsigned or_over_row(unsigned v) {
+  v |= dpp_u<0xB1>(v);   // ^1
+  v |= dpp_u<0x4E>(v);   // ^2
+  v |= dpp_u<0x141>(v);  // row_half_mirror: the other quad of the half
+  v |= dpp_u<0x140>(v);  // row_mirror: the other half
+  return v;
+}
 __device__ __forceinline__ float sum_over_g(float v) {
 #if GPN_SWAP_SUM
   float a, b;

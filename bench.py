@@ -34,7 +34,9 @@ Prints ONE JSON line (rank 0):
                 plane 1 m: ~96 % of the (sample, view) pairs visible instead of ~41 %), projector_standalone
                 (Projector.compute with the 512-channel gather materialised, B_proj of SURVEY 8(d)),
                 stress_shape (BASELINE configs[4] on one GPU: 16 views, 1296x968 images, 96 + 32 samples),
-                scannet_eval_view (BASELINE configs[2]: encoders + 76,800 rays + semantic head, seconds per view).
+                scannet_eval_view (BASELINE configs[2]: encoders + 76,800 rays + semantic head, seconds per view),
+                chunk_16384 (the headline workload at four times the rays per step: what the per-launch fixed
+                cost takes at the reference's default chunk).
   cpu_baseline  the CPU oracle (a port of the reference path) on a bounded ray sample.
 """
 import argparse
@@ -234,7 +236,7 @@ def main():
                     help="skip the other arithmetic mode, the extra legs, the full-image run and the CPU baseline "
                          "(tools/profile_round.sh: the profiled kernels are then the timed workload only)")
     ap.add_argument("--leg", default=None, choices=("single_pass_64", "dense_visibility", "projector_standalone", "stress_shape",
-                                                 "scannet_eval_view"),
+                                                 "scannet_eval_view", "chunk_16384"),
                     help="run ONLY this leg as the timed workload (profiling aid; prints the leg's block)")
     a = ap.parse_args()
     if a.only_timed:
@@ -458,7 +460,7 @@ def main():
         legs = {name: run_leg(name, a, dev, scene, rb, net, model, projector, make_step, measure,
                               stage_breakdown, world, rank)
                 for name in ("single_pass_64", "dense_visibility", "projector_standalone", "stress_shape",
-                             "scannet_eval_view")}
+                             "scannet_eval_view", "chunk_16384")}
         net.precision = a.precision
 
     # secondary metric: seconds per full image through render_single_image, results
@@ -631,6 +633,35 @@ def run_leg(name, a, dev, scene, rb, net, model, projector, make_step, measure, 
                          "stage_ms_one_step": stage_breakdown(step, mode)}
         del sc, proj, rbs, r
         torch.cuda.empty_cache()
+        return out
+    if name == "chunk_16384":
+        # the headline workload with two and four times the rays per step: what the fixed cost per launch (93
+        # launches per step, ~11 us each + ~3.5 us between them) costs at the reference's default chunk of 4096
+        from gp_nerf_amd.render_ray import render_rays
+        out = {"workload": "the headline workload with 8192 / 16384 rays per step (chunk_size is the caller's choice, "
+                           "reference render_image.py:39; results are chunk invariant bit for bit)"}
+        for big in (2 * CHUNK, 4 * CHUNK):
+            start = min((scene.H // 2) * scene.W, scene.H * scene.W - big)
+            rbb = dict(rb)
+            rbb["ray_o"], rbb["ray_d"] = scene.rays_o[start:start + big].to(dev), scene.rays_d[start:start + big].to(dev)
+
+            def step(collective=False):
+                return render_rays(rbb, model, scene.featmaps, scene.deep, projector, N_samples=N_SAMPLES,
+                                   inv_uniform=True, N_importance=N_IMPORTANCE, det=True, ret_alpha=True,
+                                   single_net=True)
+            for mode in ("fp32", "bf16x3"):
+                net.precision = mode
+                for _ in range(2):
+                    r = step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    r = step()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / steps
+                out.setdefault(mode, {})["rays_%d" % big] = {"value": big / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt}
+            del r, rbb
+            torch.cuda.empty_cache()
         return out
     if name == "scannet_eval_view":
         # BASELINE.json configs[2]: one ScanNet-shaped evaluation view through the whole chain of

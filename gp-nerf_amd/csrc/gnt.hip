@@ -42,6 +42,15 @@
 #define VA_SLOT_BYTES (4096 + 256)  // one (tile, view) pair: 16 feature rows + 64 ray_diff floats
 #define VA_DMA_OPS 5
 // cache policy of the feature-row DMA: read once per launch -> non-temporal (measured -5 %)
+#ifndef GPN_FUSE_VIEW_QP
+#define GPN_FUSE_VIEW_QP 1  // ... and k_qpos of the even layers as its third phase
+#endif
+#ifndef GPN_FUSE_RAY_FF
+#define GPN_FUSE_RAY_FF 1  // gnt_forward_impl: k_ff of the ray stage as a second phase of k_ray1 / k_ray_attn
+#endif
+#ifndef GPN_FUSE_VIEW_FF
+#define GPN_FUSE_VIEW_FF 1  // gnt_forward_impl: k_ff of the view stage as a second phase of k_view_attn
+#endif
 #ifndef VA_TILED_DMA
 #define VA_TILED_DMA 1
 #endif
@@ -778,13 +787,276 @@ k_rd_pack(const float* __restrict__ rd, const float* __restrict__ xyz, float qx,
   }
 }
 
+// ------------------------------------------------------------------------------------ feed-forward
+// LDS: W1 [256][68] | W2 [64][260] | b1 [256] | b2 [64] | gamma [64] | beta [64]
+#define FF_LD2 260
+constexpr int ff_lds_floats(bool spl) {
+  return wimg_floats(spl, 256, 4, LDW) + wimg_floats(spl, 64, 16, FF_LD2) + 256 + 64 * 3;
+}
+
+// The feed-forward block as device code shared by k_ff and by the second phase of k_view_attn (which
+// runs it on the tiles the workgroup has just written, after re-staging LDS with the FF weights).
+// Tiles of a wave: first + t * inner + i * outer (t < NTL tiles per iteration i); slot -> point through
+// `perm` when given (the visibility order of the view attention), else identity.
+struct FfLds {
+  float *W1, *W2, *b1, *b2, *gam, *bet;
+};
+template <bool SPL>
+__device__ __forceinline__ FfLds ff_lds() {
+  FfLds L;
+  L.W1 = smem;
+  L.W2 = L.W1 + wimg_floats(SPL, 256, 4, LDW);
+  L.b1 = L.W2 + wimg_floats(SPL, 64, 16, FF_LD2);
+  L.b2 = L.b1 + 256;
+  L.gam = L.b2 + 64;
+  L.bet = L.gam + 64;
+  return L;
+}
+// two-phase staging (gnt_mfma.h): every global load first (load), then the LDS images (store); as a later
+// phase of an attention kernel the loads are issued BEFORE the barrier that frees LDS
+template <bool SPL, int TPB>
+struct FfStager {
+  WStage<SPL, 256, 4, TPB> s1;
+  WStage<SPL, 64, 16, TPB> s2;
+  VecStage<256, TPB> v1;
+  VecStage<64, TPB> v2, vg, vb;
+  __device__ __forceinline__ void load(const float* __restrict__ norm_w, const float* __restrict__ norm_b,
+                                       const gpn_linear_t& fc1, const gpn_linear_t& fc2, int tid) {
+    s1.load(fc1.w, 256, 64, tid), s2.load(fc2.w, 64, 256, tid);
+    v1.load(fc1.b, 256, tid), v2.load(fc2.b, 64, tid), vg.load(norm_w, 64, tid), vb.load(norm_b, 64, tid);
+  }
+  __device__ __forceinline__ void store(const FfLds& L, int tid) const {
+    s1.store(L.W1, LDW, tid), s2.store(L.W2, FF_LD2, tid);
+    STAMP(9);
+    v1.store(L.b1, tid), v2.store(L.b2, tid), vg.store(L.gam, tid), vb.store(L.bet, tid);
+  }
+};
+template <bool SPL, int TPB>
+__device__ __forceinline__ void ff_stage(const FfLds& L, const float* __restrict__ norm_w,
+                                         const float* __restrict__ norm_b, const gpn_linear_t& fc1,
+                                         const gpn_linear_t& fc2, int tid) {
+  FfStager<SPL, TPB> st;
+  st.load(norm_w, norm_b, fc1, fc2, tid);
+  st.store(L, tid);
+}
+// A wave's tiles are numbered u = 0 .. nu-1; `pt(u, j, n, ok)` gives the point (row of x) of lane j of
+// tile u and whether it is a real point (else: any valid row, never stored).
+// split mode: the input rows of the wave's tiles u0 .. u0+NTL-1 (the first ones are requested before /
+// while the weights are staged)
+template <class PT>
+__device__ __forceinline__ void ff_prefetch(f4 (&xpre)[FF_NTL][4], const float* __restrict__ x_in, long long u0,
+                                            int lane, PT&& pt) {
+#pragma unroll
+  for (int t = 0; t < FF_NTL; ++t) {
+    long long n;
+    bool ok;
+    pt(u0 + t, lane & 15, n, ok);
+#pragma unroll
+    for (int T = 0; T < 4; ++T) xpre[t][T] = ld4(x_in + (size_t)n * C64 + 16 * T + 4 * (lane >> 4));
+  }
+}
+template <bool SPL, class PT>
+__device__ __forceinline__ void ff_run(const FfLds& L, [[maybe_unused]] f4 (&xpre)[FF_NTL][4],
+                                       const float* __restrict__ x_in, float* x_out, long long nu, int lane,
+                                       PT&& pt) {
+  const int j = lane & 15, g = lane >> 4;
+  if constexpr (SPL) {
+    // FF_NTL point tiles per wave iteration; the hidden layer is produced and consumed in four 64-wide
+    // chunks, so the 256 hidden values of a point never exist at once
+    constexpr int NTL = FF_NTL;
+    const bf8* w1p = reinterpret_cast<const bf8*>(L.W1) + lane;
+    const bf8* w2p = reinterpret_cast<const bf8*>(L.W2) + lane;
+    // the input tiles of the next iteration are loaded one iteration ahead (the first ones: ff_prefetch)
+    for (long long u = 0; u < nu; u += NTL) {
+      long long n[NTL];
+      bool ok[NTL];
+      XS xs[NTL][2];
+      f4 y[NTL][4], x[NTL][4];
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) {
+        pt(u + t, j, n[t], ok[t]);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) x[t][T] = xpre[t][T];
+      }
+      ff_prefetch(xpre, x_in, u + NTL, lane, pt);
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) {
+        f4 xn[4];
+        layernorm_T(x[t], xn, L.gam, L.bet, 1e-6f, lane);
+        xs[t][0] = split8(xn[0], xn[1]);
+        xs[t][1] = split8(xn[2], xn[3]);
+#pragma unroll
+        for (int M = 0; M < 4; ++M) y[t][M] = ld4(L.b2 + 16 * M + 4 * g);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        f4 h[NTL][4];
+#pragma unroll
+        for (int t = 0; t < NTL; ++t)
+#pragma unroll
+          for (int M = 0; M < 4; ++M) h[t][M] = ld4(L.b1 + 64 * c + 16 * M + 4 * g);
+        lin_S2<2, 2, 4, NTL>(w1p + (4 * c * 2) * 128, xs, h);  // rows 64c.., all 64 inputs
+        XS hs[NTL][2];
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+          hs[t][0] = split8(f4_relu_t<true>(h[t][0]), f4_relu_t<true>(h[t][1]));
+          hs[t][1] = split8(f4_relu_t<true>(h[t][2]), f4_relu_t<true>(h[t][3]));
+        }
+        lin_S2<8, 2, 4, NTL>(w2p + (2 * c) * 128, hs, y);      // all 64 rows, hidden 64c..64c+63
+      }
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) {
+        if (ok[t]) {
+#pragma unroll
+          for (int M = 0; M < 4; ++M) {
+            FF_ST(x_out + (size_t)n[t] * C64 + 16 * M + 4 * g, y[t][M] + x[t][M]);
+          }
+        }
+      }
+    }
+  } else {
+    for (long long u = 0; u < nu; ++u) {
+      long long n;
+      bool valid;
+      pt(u, j, n, valid);
+      f4 x[4], xn[4], h[16], y[4];
+#pragma unroll
+      for (int T = 0; T < 4; ++T) x[T] = ld4(x_in + (size_t)n * C64 + 16 * T + 4 * g);
+      layernorm_T(x, xn, L.gam, L.bet, 1e-6f, lane);
+#pragma unroll
+      for (int M = 0; M < 16; ++M) h[M] = ld4(L.b1 + 16 * M + 4 * g);
+      lin_T<4, 16>(L.W1, LDW, xn, h, lane);
+#pragma unroll
+      for (int M = 0; M < 16; ++M) h[M] = f4_relu(h[M]);
+#pragma unroll
+      for (int M = 0; M < 4; ++M) y[M] = ld4(L.b2 + 16 * M + 4 * g);
+      lin_T<16, 4>(L.W2, FF_LD2, h, y, lane);
+      if (valid) {
+#pragma unroll
+        for (int M = 0; M < 4; ++M) st4(x_out + (size_t)n * C64 + 16 * M + 4 * g, y[M] + x[M]);
+      }
+    }
+  }
+}
+// tile u of a wave = point tile `first + (u % NTL) * inner + (u / NTL) * outer` of a [N, 64] array, slot -> point
+// through `perm` when given (the visibility order of the view attention), else identity
+template <int NTL>  // tiles per iteration: FF_NTL in split mode, 1 in fp32 mode
+struct FfTilePt {
+  const int* perm;
+  long long N, first, inner, outer;
+  __device__ __forceinline__ void operator()(long long u, int j, long long& n, bool& ok) const {
+    const long long tile = first + (u % NTL) * inner + (u / NTL) * outer;
+    const long long slot = tile * 16 + j, sc = slot < N ? slot : N - 1;
+    ok = slot < N;
+    n = perm != nullptr ? (long long)perm[sc] : sc;
+  }
+};
+// tiles a wave walks: u < nu  <=>  first + (u / NTL) * outer < ntiles  (a group is cut at its first tile)
+__device__ __forceinline__ long long ff_tile_count(long long ntiles, long long first, long long outer) {
+  return first < ntiles ? ((ntiles - first + outer - 1) / outer) * FF_NTL : 0;
+}
+
+// ------------------------------------------------------------------------------------ q positional MLP
+// input = [q (64) | emb_pt (64) | emb_ray of the point's ray (64)] = 192 channels (k_posenc); LDS: W0 [64][196] | W2 [64][68] | b0 | b2
+#define QP_LD0 196
+constexpr int qp_lds_floats(bool spl) {
+  return wimg_floats(spl, 64, 12, QP_LD0) + wimg_floats(spl, 64, 4, LDW) + 128;
+}
+
+struct QpLds {
+  float *W0, *W2, *b0, *b2;
+};
+template <bool SPL>
+__device__ __forceinline__ QpLds qp_lds() {
+  QpLds L;
+  L.W0 = smem;
+  L.W2 = L.W0 + wimg_floats(SPL, 64, 12, QP_LD0);
+  L.b0 = L.W2 + wimg_floats(SPL, 64, 4, LDW);
+  L.b2 = L.b0 + 64;
+  return L;
+}
+template <bool SPL, int TPB>
+struct QpStager {  // (see FfStager)
+  WStage<SPL, 64, 12, TPB> s0;
+  WStage<SPL, 64, 4, TPB> s2;
+  VecStage<64, TPB> v0, v2;
+  __device__ __forceinline__ void load(const gpn_linear_t& fc0, const gpn_linear_t& fc2, int tid) {
+    s0.load(fc0.w, 64, 190, tid), s2.load(fc2.w, 64, 64, tid);
+    v0.load(fc0.b, 64, tid), v2.load(fc2.b, 64, tid);
+  }
+  __device__ __forceinline__ void store(const QpLds& L, int tid) const {
+    s0.store(L.W0, QP_LD0, tid), s2.store(L.W2, LDW, tid);
+    v0.store(L.b0, tid), v2.store(L.b2, tid);
+  }
+};
+template <bool SPL, int TPB>
+__device__ __forceinline__ void qp_stage(const QpLds& L, const gpn_linear_t& fc0, const gpn_linear_t& fc2, int tid) {
+  QpStager<SPL, TPB> st;
+  st.load(fc0, fc2, tid);
+  st.store(L, tid);
+}
+// the MLP on a wave's tiles u = 0 .. nu-1 (`pt` as in ff_run); q_in and q_out may be the same array
+template <bool SPL, class PT>
+__device__ __forceinline__ void qp_run(const QpLds& L, const float* q_in, const float* __restrict__ emb_pt,
+                                       const float* __restrict__ emb_ray, int S, float* q_out, long long nu, int lane,
+                                       PT&& pt) {
+  const int j = lane & 15, g = lane >> 4;
+  for (long long u = 0; u < nu; ++u) {
+    // (prefetching the next tile's 48 input registers was measured 6 % slower: the copies cost more
+    // than the exposed latency)
+    long long n;
+    bool valid;
+    pt(u, j, n, valid);
+    f4 x[12], h[4], y[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) x[T] = ld4(q_in + (size_t)n * C64 + 16 * T + 4 * g);
+#pragma unroll
+    for (int T = 0; T < 4; ++T) x[4 + T] = ld4(emb_pt + (size_t)n * GPN_EMB_HALF + 16 * T + 4 * g);
+    const int ray = (int)n / S;  // N fits an int (C-ABI)
+#pragma unroll
+    for (int T = 0; T < 4; ++T) x[8 + T] = ld4(emb_ray + (size_t)ray * GPN_EMB_HALF + 16 * T + 4 * g);
+#pragma unroll
+    for (int M = 0; M < 4; ++M) h[M] = ld4(L.b0 + 16 * M + 4 * g);
+    lin<SPL, 12, 4>(L.W0, QP_LD0, x, h, lane);
+#pragma unroll
+    for (int M = 0; M < 4; ++M) {
+      h[M] = f4_relu_t<SPL>(h[M]);
+      y[M] = ld4(L.b2 + 16 * M + 4 * g);
+    }
+    lin<SPL, 4, 4>(L.W2, LDW, h, y, lane);
+    if (valid) {
+#pragma unroll
+      for (int M = 0; M < 4; ++M) st4(q_out + (size_t)n * C64 + 16 * M + 4 * g, y[M]);
+    }
+  }
+}
+
+// third phase of k_view_attn on even layers (qp_out != nullptr): q = q_fcs[l](cat(q, emb_pt, emb_ray)) on the
+// same tiles, LDS re-staged once more
+template <bool SPL, int TPB, class PT>
+__device__ __forceinline__ void qp_phase(const gpn_linear_t& fc0, const gpn_linear_t& fc2, const float* q,
+                                         const float* __restrict__ emb_pt, const float* __restrict__ emb_ray, int S,
+                                         float* qp_out, long long nu, int tid, PT&& pt) {
+  const QpLds Q = qp_lds<SPL>();
+  QpStager<SPL, TPB> st;
+  st.load(fc0, fc2, tid);  // in flight across the barrier
+  __syncthreads();  // every wave is done with the feed-forward weights
+  st.store(Q, tid);
+  __syncthreads();
+  qp_run<SPL>(Q, q, emb_pt, emb_ray, S, qp_out, nu, tid & 63, pt);
+}
+
 template <bool SPL, bool FOLD, bool TILED = false>
 __global__ void __launch_bounds__(VA_TPB)
 k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __restrict__ feat,
             const float* __restrict__ ray_diff, const float* __restrict__ mask,
             const int* __restrict__ perm, long long N, int V, float* __restrict__ q_out,
             float* __restrict__ hidden, int hidden_ld, float* __restrict__ stats, int stats_ld,
-            int layout) {
+            int layout, float* ff_out, gpn_linear_t qfc0, gpn_linear_t qfc2, const float* __restrict__ emb_pt,
+            const float* __restrict__ emb_ray, int S, float* qp_out) {
+  // ff_out != nullptr: the layer's feed-forward block runs as a second phase of this launch, on the tiles
+  // this workgroup has just written (q_out -> ff_out; LDS re-staged with the FF weights in between): one
+  // launch, one ramp and one tail instead of two, and the rows come back from L2.
   // layout & 1: `ray_diff` is the tile-major image written by k_rd_pack ([tile][view][component][16
   // points of the tile, in slot order]): the 64 floats of a (tile, view) pair are ONE contiguous 256-byte
   // run (two whole lines) instead of 16 sixteen-byte entries in 16 different 64-byte sectors.
@@ -1016,7 +1288,8 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
   __syncthreads();
 
   STAMP(2);
-  if (!has_tile) return;
+  if (!has_tile && ff_out == nullptr) return;
+  auto attention_phase = [&]() {
   const float p0w = L.P0[j * 4 + g];  // A operand of the 4 -> 8 layer: W[i = j][k = g]
 
   unsigned long long redo_lanes = 0;  // lanes (points) of the current tile to redo in the online form
@@ -1307,143 +1580,44 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last (unused) ring fills land before the wave ends
   VA_MARK(5);
   VA_END();
+  };
+  if (has_tile) attention_phase();
   STAMP(5);
+  if (ff_out != nullptr) {  // (wave-uniform: a kernel argument)
+    const long long tile0 = (long long)blockIdx.x * (VA_TPB / 64) + wave;
+    const FfTilePt<SPL ? FF_NTL : 1> pt = {perm, N, tile0, tstride, SPL ? tstride * FF_NTL : tstride};
+    const long long nu = SPL ? ff_tile_count(ntiles, tile0, tstride * FF_NTL)
+                             : (tile0 < ntiles ? (ntiles - tile0 + tstride - 1) / tstride : 0);
+    ff_phase<SPL, VA_TPB>(Lw.ff_norm_w, Lw.ff_norm_b, Lw.ff1, Lw.ff2, q_out, ff_out, nu, tid, pt);
+    if (qp_out != nullptr)  // (only after the feed-forward phase; wave-uniform)
+      qp_phase<SPL, VA_TPB>(qfc0, qfc2, ff_out, emb_pt, emb_ray, S, qp_out, nu, tid, pt);
+  }
 }
 
-// ------------------------------------------------------------------------------------ feed-forward
-// LDS: W1 [256][68] | W2 [64][260] | b1 [256] | b2 [64] | gamma [64] | beta [64]
-#define FF_LD2 260
-constexpr int ff_lds_floats(bool spl) {
-  return wimg_floats(spl, 256, 4, LDW) + wimg_floats(spl, 64, 16, FF_LD2) + 256 + 64 * 3;
-}
-
+// ------------------------------------------------------------------------------------ feed-forward (kernel)
 template <bool SPL>
 __global__ void __launch_bounds__(FF_TPB)
 k_ff(const float* __restrict__ norm_w, const float* __restrict__ norm_b, gpn_linear_t fc1,
      gpn_linear_t fc2, const float* __restrict__ x_in, long long N, float* __restrict__ x_out) {
-  float* W1 = smem;
-  float* W2 = W1 + wimg_floats(SPL, 256, 4, LDW);
-  float* b1 = W2 + wimg_floats(SPL, 64, 16, FF_LD2);
-  float* b2 = b1 + 256;
-  float* gam = b2 + 64;
-  float* bet = gam + 64;
+  const FfLds L = ff_lds<SPL>();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   STAMP(8);
   WAVE_T(0);
-  // split mode: the first input tiles are requested before the weights (their HBM latency then
-  // runs under the staging instead of after the barrier)
-  [[maybe_unused]] f4 xpre[FF_NTL][4];
-  if constexpr (SPL) {
-    const long long pr0 = (long long)blockIdx.x * (FF_TPB / 64) + wave;
-#pragma unroll
-    for (int t = 0; t < FF_NTL; ++t) {
-      const long long np = (pr0 * FF_NTL + t) * 16 + (lane & 15), npc = np < N ? np : N - 1;
-#pragma unroll
-      for (int T = 0; T < 4; ++T) xpre[t][T] = ld4(x_in + (size_t)npc * C64 + 16 * T + 4 * (lane >> 4));
-    }
-  }
-  {  // two-phase staging (gnt_mfma.h): every global load first, then the LDS images
-    WStage<SPL, 256, 4, FF_TPB> s1;
-    WStage<SPL, 64, 16, FF_TPB> s2;
-    VecStage<256, FF_TPB> v1;
-    VecStage<64, FF_TPB> v2, vg, vb;
-    s1.load(fc1.w, 256, 64, tid), s2.load(fc2.w, 64, 256, tid);
-    v1.load(fc1.b, 256, tid), v2.load(fc2.b, 64, tid), vg.load(norm_w, 64, tid), vb.load(norm_b, 64, tid);
-    s1.store(W1, LDW, tid), s2.store(W2, FF_LD2, tid);
-    STAMP(9);
-    v1.store(b1, tid), v2.store(b2, tid), vg.store(gam, tid), vb.store(bet, tid);
-  }
+  const long long w0 = (long long)blockIdx.x * (FF_TPB / 64) + wave, stride = (long long)gridDim.x * (FF_TPB / 64);
+  const long long ntiles = (N + 15) >> 4;
+  // split mode: a wave takes FF_NTL consecutive tiles per iteration; the first input tiles are requested
+  // before the weights (their HBM latency then runs under the staging instead of after the barrier)
+  const FfTilePt<SPL ? FF_NTL : 1> pt = {nullptr, N, SPL ? w0 * FF_NTL : w0, 1, SPL ? stride * FF_NTL : stride};
+  const long long nu = SPL ? ff_tile_count(ntiles, w0 * FF_NTL, stride * FF_NTL)
+                           : (w0 < ntiles ? (ntiles - w0 + stride - 1) / stride : 0);
+  f4 xpre[FF_NTL][4];
+  if constexpr (SPL) ff_prefetch(xpre, x_in, 0, lane, pt);
+  ff_stage<SPL, FF_TPB>(L, norm_w, norm_b, fc1, fc2, tid);
   __syncthreads();
   STAMP(10);
-  const int j = lane & 15, g = lane >> 4;
-  const long long ntiles = (N + 15) >> 4;
-  if constexpr (SPL) {
-    // FF_NTL point tiles per wave; the hidden layer is produced and consumed in four 64-wide
-    // chunks, so the 256 hidden values of a point never exist at once
-    constexpr int NTL = FF_NTL;
-    const bf8* w1p = reinterpret_cast<const bf8*>(W1) + lane;
-    const bf8* w2p = reinterpret_cast<const bf8*>(W2) + lane;
-    const long long ngroups = (ntiles + NTL - 1) / NTL;
-    const long long stride = (long long)gridDim.x * (FF_TPB / 64);
-    long long pr = (long long)blockIdx.x * (FF_TPB / 64) + wave;
-    // the input tiles of the next iteration are loaded one iteration ahead (the first ones: above)
-    for (; pr < ngroups; pr += stride) {
-      long long n[NTL];
-      XS xs[NTL][2];
-      f4 y[NTL][4], x[NTL][4];
-#pragma unroll
-      for (int t = 0; t < NTL; ++t) {
-        n[t] = (pr * NTL + t) * 16 + j;
-#pragma unroll
-        for (int T = 0; T < 4; ++T) x[t][T] = xpre[t][T];
-      }
-#pragma unroll
-      for (int t = 0; t < NTL; ++t) {
-        const long long np = ((pr + stride) * NTL + t) * 16 + j, npc = np < N ? np : N - 1;
-#pragma unroll
-        for (int T = 0; T < 4; ++T) xpre[t][T] = ld4(x_in + (size_t)npc * C64 + 16 * T + 4 * g);
-      }
-#pragma unroll
-      for (int t = 0; t < NTL; ++t) {
-        f4 xn[4];
-        layernorm_T(x[t], xn, gam, bet, 1e-6f, lane);
-        xs[t][0] = split8(xn[0], xn[1]);
-        xs[t][1] = split8(xn[2], xn[3]);
-#pragma unroll
-        for (int M = 0; M < 4; ++M) y[t][M] = ld4(b2 + 16 * M + 4 * g);
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        f4 h[NTL][4];
-#pragma unroll
-        for (int t = 0; t < NTL; ++t)
-#pragma unroll
-          for (int M = 0; M < 4; ++M) h[t][M] = ld4(b1 + 64 * c + 16 * M + 4 * g);
-        lin_S2<2, 2, 4, NTL>(w1p + (4 * c * 2) * 128, xs, h);  // rows 64c.., all 64 inputs
-        XS hs[NTL][2];
-#pragma unroll
-        for (int t = 0; t < NTL; ++t) {
-          hs[t][0] = split8(f4_relu_t<true>(h[t][0]), f4_relu_t<true>(h[t][1]));
-          hs[t][1] = split8(f4_relu_t<true>(h[t][2]), f4_relu_t<true>(h[t][3]));
-        }
-        lin_S2<8, 2, 4, NTL>(w2p + (2 * c) * 128, hs, y);      // all 64 rows, hidden 64c..64c+63
-      }
-#pragma unroll
-      for (int t = 0; t < NTL; ++t) {
-        if (n[t] < N) {
-#pragma unroll
-          for (int M = 0; M < 4; ++M) {
-            FF_ST(x_out + (size_t)n[t] * C64 + 16 * M + 4 * g, y[t][M] + x[t][M]);
-          }
-        }
-      }
-    }
-    STAMP(11);
-    WAVE_T(1);
-  } else {
-    for (long long tile = (long long)blockIdx.x * (FF_TPB / 64) + wave; tile < ntiles;
-         tile += (long long)gridDim.x * (FF_TPB / 64)) {
-      const long long n = tile * 16 + j;
-      const bool valid = n < N;
-      const long long nc = valid ? n : N - 1;
-      f4 x[4], xn[4], h[16], y[4];
-#pragma unroll
-      for (int T = 0; T < 4; ++T) x[T] = ld4(x_in + (size_t)nc * C64 + 16 * T + 4 * g);
-      layernorm_T(x, xn, gam, bet, 1e-6f, lane);
-#pragma unroll
-      for (int M = 0; M < 16; ++M) h[M] = ld4(b1 + 16 * M + 4 * g);
-      lin_T<4, 16>(W1, LDW, xn, h, lane);
-#pragma unroll
-      for (int M = 0; M < 16; ++M) h[M] = f4_relu(h[M]);
-#pragma unroll
-      for (int M = 0; M < 4; ++M) y[M] = ld4(b2 + 16 * M + 4 * g);
-      lin_T<16, 4>(W2, FF_LD2, h, y, lane);
-      if (valid) {
-#pragma unroll
-        for (int M = 0; M < 4; ++M) st4(x_out + (size_t)n * C64 + 16 * M + 4 * g, y[M] + x[M]);
-      }
-    }
-  }
+  ff_run<SPL>(L, xpre, x_in, x_out, nu, lane, pt);
+  STAMP(11);
+  WAVE_T(1);
 }
 
 // Split-mode feed-forward on 32x32x16 MFMAs (gnt_mfma.h, "32x32x16 form"): one 32-point tile per wave
@@ -1632,64 +1806,50 @@ k_ff32(const float* __restrict__ norm_w, const float* __restrict__ norm_b, gpn_l
   }
 }
 
-// ------------------------------------------------------------------------------------ q positional MLP
-// input = [q (64) | emb_pt (64) | emb_ray of the point's ray (64)] = 192 channels (k_posenc); LDS: W0 [64][196] | W2 [64][68] | b0 | b2
-#define QP_LD0 196
-constexpr int qp_lds_floats(bool spl) {
-  return wimg_floats(spl, 64, 12, QP_LD0) + wimg_floats(spl, 64, 4, LDW) + 128;
-}
-
+// ------------------------------------------------------------------------------------ q positional MLP (kernel)
 template <bool SPL>
 __global__ void __launch_bounds__(QP_TPB)
 k_qpos(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ q_in,
        const float* __restrict__ emb_pt, const float* __restrict__ emb_ray, long long N, int S,
        float* __restrict__ q_out) {
-  float* W0 = smem;
-  float* W2 = W0 + wimg_floats(SPL, 64, 12, QP_LD0);
-  float* b0 = W2 + wimg_floats(SPL, 64, 4, LDW);
-  float* b2 = b0 + 64;
+  const QpLds L = qp_lds<SPL>();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  {  // two-phase staging (gnt_mfma.h): every global load first, then the LDS images
-    WStage<SPL, 64, 12, QP_TPB> s0;
-    WStage<SPL, 64, 4, QP_TPB> s2;
-    VecStage<64, QP_TPB> v0, v2;
-    s0.load(fc0.w, 64, 190, tid), s2.load(fc2.w, 64, 64, tid);
-    v0.load(fc0.b, 64, tid), v2.load(fc2.b, 64, tid);
-    s0.store(W0, QP_LD0, tid), s2.store(W2, LDW, tid);
-    v0.store(b0, tid), v2.store(b2, tid);
-  }
+  qp_stage<SPL, QP_TPB>(L, fc0, fc2, tid);
   __syncthreads();
-  const int j = lane & 15, g = lane >> 4;
   const long long ntiles = (N + 15) >> 4;
-  const long long tstride = (long long)gridDim.x * (QP_TPB / 64);
-  for (long long tile = (long long)blockIdx.x * (QP_TPB / 64) + wave; tile < ntiles; tile += tstride) {
-    // (prefetching the next tile's 48 input registers was measured 6 % slower: the copies cost more
-    // than the exposed latency)
-    const long long n = tile * 16 + j;
-    const bool valid = n < N;
-    const long long nc = valid ? n : N - 1;
-    f4 x[12], h[4], y[4];
-#pragma unroll
-    for (int T = 0; T < 4; ++T) x[T] = ld4(q_in + (size_t)nc * C64 + 16 * T + 4 * g);
-#pragma unroll
-    for (int T = 0; T < 4; ++T) x[4 + T] = ld4(emb_pt + (size_t)nc * GPN_EMB_HALF + 16 * T + 4 * g);
-    const int ray = (int)nc / S;  // N fits an int (C-ABI)
-#pragma unroll
-    for (int T = 0; T < 4; ++T) x[8 + T] = ld4(emb_ray + (size_t)ray * GPN_EMB_HALF + 16 * T + 4 * g);
-#pragma unroll
-    for (int M = 0; M < 4; ++M) h[M] = ld4(b0 + 16 * M + 4 * g);
-    lin<SPL, 12, 4>(W0, QP_LD0, x, h, lane);
-#pragma unroll
-    for (int M = 0; M < 4; ++M) {
-      h[M] = f4_relu_t<SPL>(h[M]);
-      y[M] = ld4(b2 + 16 * M + 4 * g);
-    }
-    lin<SPL, 4, 4>(W2, LDW, h, y, lane);
-    if (valid) {
-#pragma unroll
-      for (int M = 0; M < 4; ++M) st4(q_out + (size_t)n * C64 + 16 * M + 4 * g, y[M]);
-    }
+  const long long tstride = (long long)gridDim.x * (QP_TPB / 64), t0 = (long long)blockIdx.x * (QP_TPB / 64) + wave;
+  const FfTilePt<1> pt = {nullptr, N, t0, 0, tstride};
+  qp_run<SPL>(L, q_in, emb_pt, emb_ray, S, q_out, t0 < ntiles ? (ntiles - t0 + tstride - 1) / tstride : 0, lane, pt);
+}
+
+// Feed-forward phase of the ray kernels: tile u of a wave = samples 16 t .. 16 t + 15 of ray
+// `ray0 + (u / TPR) * rstride` with t = t0 + u % TPR (TPR tiles of a ray per wave: NT in k_ray1, 1 in k_ray_attn)
+template <int TPR>
+struct FfRayPt {
+  int R, S, ray0, rstride, t0;
+  __device__ __forceinline__ void operator()(long long u, int j, long long& n, bool& ok) const {
+    const int ui = (int)u, ray = ray0 + (ui / TPR) * rstride, s = 16 * (t0 + ui % TPR) + j;
+    ok = ray < R && s < S;
+    n = (long long)(ray < R ? ray : R - 1) * S + (s < S ? s : S - 1);
   }
+};
+// second phase of a ray kernel (ff_out != nullptr): the layer's feed-forward block on the tiles this
+// workgroup has just written, after re-staging LDS with the FF weights (see k_view_attn)
+template <bool SPL, int TPB, class PT>
+__device__ __forceinline__ void ff_phase(const float* __restrict__ norm_w, const float* __restrict__ norm_b,
+                                         const gpn_linear_t& fc1, const gpn_linear_t& fc2, const float* x, float* ff_out,
+                                         long long nu, int tid, PT&& pt) {
+  const int lane = tid & 63;
+  const FfLds F = ff_lds<SPL>();
+  f4 xpre[FF_NTL][4];
+  // this wave's own stores of x are in program order before these loads
+  if constexpr (SPL) ff_prefetch(xpre, x, 0, lane, pt);
+  FfStager<SPL, TPB> st;
+  st.load(norm_w, norm_b, fc1, fc2, tid);  // in flight across the barrier
+  __syncthreads();  // every wave is done with the attention weights / keys / values in LDS
+  st.store(F, tid);
+  __syncthreads();
+  ff_run<SPL>(F, xpre, x, ff_out, nu, lane, pt);
 }
 
 // ------------------------------------------------------------------------------------ ray attention
@@ -1722,7 +1882,7 @@ template <int NT, bool SPL>
 __global__ void __launch_bounds__(RayCfg<NT>::THREADS)
 k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
            float* __restrict__ x_out, float* __restrict__ abar, int abar_ld,
-           float* __restrict__ weights) {
+           float* __restrict__ weights, float* ff_out) {
   // S (<= SP) real samples per ray; keys >= S are masked out of the softmax, queries >= S are
   // computed on clamped data and never stored.
   using Cfg = RayCfg<NT>;
@@ -2000,6 +2160,12 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
   }
   RA_MARK(4);
   RA_END();
+  if (ff_out != nullptr) {  // (wave-uniform: a kernel argument)
+    const int ngrp = (R + RPW - 1) / RPW;
+    const long long nu = (int)blockIdx.x < ngrp ? (ngrp - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const FfRayPt<1> pt = {R, S, (int)blockIdx.x * RPW + slot, (int)gridDim.x * RPW, t};
+    ff_phase<SPL, NTHR>(Lw.ff_norm_w, Lw.ff_norm_b, Lw.ff1, Lw.ff2, x_out, ff_out, nu, tid, pt);
+  }
 }
 
 // ---- k_ray1: ONE wave per ray (instantiated for NT <= 4, used for NT <= 3, i.e. S <= 48).  The keys and values of a ray never leave the
@@ -2023,7 +2189,7 @@ constexpr int ray1_lds_floats(bool spl) { return 4 * wimg_floats(spl, 64, 4, LDW
 template <int NT, bool SPL>
 __global__ void __launch_bounds__(RAY1_WAVES * 64, RAY1_MINW)
 k_ray1(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S, float* __restrict__ x_out,
-       float* __restrict__ abar, int abar_ld, float* __restrict__ weights) {
+       float* __restrict__ abar, int abar_ld, float* __restrict__ weights, float* ff_out) {
   constexpr int NTHR = RAY1_WAVES * 64;
   float* Wq = smem;
   float* Wk = Wq + wimg_floats(SPL, 64, 4, LDW);
@@ -2238,6 +2404,12 @@ k_ray1(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S, float* 
           if (kt < NT && key < S) abar[(rbase + key) * abar_ld + h] = csum[h][grp] / (float)S;
         }
     }
+  }
+  if (ff_out != nullptr) {  // (wave-uniform: a kernel argument)
+    const int ray0 = blockIdx.x * RAY1_WAVES + wave, rstride = (int)gridDim.x * RAY1_WAVES;
+    const long long nu = ray0 < R ? (long long)((R - ray0 + rstride - 1) / rstride) * NT : 0;
+    const FfRayPt<NT> pt = {R, S, ray0, rstride, 0};
+    ff_phase<SPL, NTHR>(Lw.ff_norm_w, Lw.ff_norm_b, Lw.ff1, Lw.ff2, x_out, ff_out, nu, tid, pt);
   }
 }
 
@@ -2742,7 +2914,10 @@ extern "C" int gpn_view_fold(const gpn_view_layer_t* L, float* out, gpn_stream_t
 static int view_attn_launch(const gpn_view_layer_t* L, const float* q_in, const float* feat,
                             const float* ray_diff, int layout, const float* mask, const int32_t* perm, int N,
                             int V, float* q_out, float* hidden, int hidden_ld, float* stats,
-                            int stats_ld, int precision, gpn_stream_t stream) {
+                            int stats_ld, int precision, gpn_stream_t stream, float* ff_out = nullptr,
+                            const gpn_linear_t* qfc0 = nullptr, const gpn_linear_t* qfc2 = nullptr,
+                            const float* emb_pt = nullptr, const float* emb_ray = nullptr, int S = 1,
+                            float* qp_out = nullptr) {
   GPN_REQUIRE_PREC(precision, "gpn_view_attn");
   if (N == 0) return GPN_OK;  // empty batch (pointers may be null)
   GPN_REQUIRE(L && q_in && feat && ray_diff && mask && q_out, "gpn_view_attn: null pointer");
@@ -2765,6 +2940,11 @@ static int view_attn_launch(const gpn_view_layer_t* L, const float* q_in, const 
   const bool fold = L->folded != nullptr;
   const size_t lds = sizeof(float) * view_lds_floats(spl) + (VA_TPB / 64) * 2 * VA_SLOT_BYTES;
   const bool tiled = VA_TILED_DMA && fold && layout == 3;  // the fused path: scalar-base DMA addressing
+  GPN_REQUIRE(ff_out == nullptr || (L->ff1.w && L->ff2.w && L->ff_norm_w && L->ff_norm_b),
+              "gpn_view_attn: fused feed-forward without its weights");
+  GPN_REQUIRE(qp_out == nullptr || (ff_out && qfc0 && qfc2 && qfc0->w && qfc2->w && emb_pt && emb_ray && S >= 1),
+              "gpn_view_attn: fused q MLP needs the feed-forward phase, its weights and the encodings");
+  const gpn_linear_t q0_ = qp_out ? *qfc0 : gpn_linear_t{}, q2_ = qp_out ? *qfc2 : gpn_linear_t{};
   const void* fn = tiled ? (spl ? reinterpret_cast<const void*>(k_view_attn<true, true, true>)
                                 : reinterpret_cast<const void*>(k_view_attn<false, true, true>))
                    : spl ? (fold ? reinterpret_cast<const void*>(k_view_attn<true, true>)
@@ -2779,22 +2959,22 @@ static int view_attn_launch(const gpn_view_layer_t* L, const float* q_in, const 
   hipStream_t st = (hipStream_t)stream;
   if (tiled && spl)
     hipLaunchKernelGGL((k_view_attn<true, true, true>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
-                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, layout);
+                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, layout, ff_out, q0_, q2_, emb_pt, emb_ray, S, qp_out);
   else if (tiled)
     hipLaunchKernelGGL((k_view_attn<false, true, true>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
-                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, layout);
+                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, layout, ff_out, q0_, q2_, emb_pt, emb_ray, S, qp_out);
   else if (fold && spl)
     hipLaunchKernelGGL((k_view_attn<true, true>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
-                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, layout);
+                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, layout, ff_out, q0_, q2_, emb_pt, emb_ray, S, qp_out);
   else if (fold)
     hipLaunchKernelGGL((k_view_attn<false, true>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
-                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, layout);
+                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, layout, ff_out, q0_, q2_, emb_pt, emb_ray, S, qp_out);
   else if (spl)
     hipLaunchKernelGGL((k_view_attn<true, false>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
-                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, layout);
+                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, layout, ff_out, q0_, q2_, emb_pt, emb_ray, S, qp_out);
   else
     hipLaunchKernelGGL((k_view_attn<false, false>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
-                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, layout);
+                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, layout, ff_out, q0_, q2_, emb_pt, emb_ray, S, qp_out);
   GPN_LAUNCH_CHECK("k_view_attn");
   return GPN_OK;
 }
@@ -2885,46 +3065,49 @@ extern "C" int gpn_qpos(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const 
 
 template <int NT, bool SPL>
 static int launch_ray_attn_p(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,
-                             float* abar, int abar_ld, float* weights, hipStream_t stream) {
+                             float* abar, int abar_ld, float* weights, hipStream_t stream, float* ff_out) {
+  // (ff_out: the feed-forward phase re-stages LDS with its own weights: the launch needs the larger image)
+  const size_t lds_ff = ff_out ? sizeof(float) * ff_lds_floats(SPL) : 0;
 #if GPN_RAY1
   // one wave per ray, keys / values in registers (k_ray1).  Per launch at R = 4096 (rocprofv3): S = 48 fp32
   // 111 -> 89 us, bf16x3 59 -> 52.5 us; S = 64 (the 128 key / value registers leave the compiler no room)
   // fp32 124.5 -> 125, bf16x3 68.5 -> 72 us: k_ray_attn stays the kernel of S > 48
   if constexpr (NT <= RAY1_MAXNT) {
-    const size_t lds1 = sizeof(float) * ray1_lds_floats(SPL);
+    const size_t lds1 = std::max(sizeof(float) * ray1_lds_floats(SPL), lds_ff);
     int rc1 = set_lds_limit(reinterpret_cast<const void*>(k_ray1<NT, SPL>), lds1);
     if (rc1) return rc1;
     const int grid1 = persistent_grid(((long long)R + RAY1_WAVES - 1) / RAY1_WAVES);
     GpnStageTimer timer_k_ray1_(GPN_ST_RAY_ATTN, stream);
     hipLaunchKernelGGL((k_ray1<NT, SPL>), dim3(grid1), dim3(RAY1_WAVES * 64), lds1, stream, *L, x_in, R, S, x_out,
-                       abar, abar_ld, weights);
+                       abar, abar_ld, weights, ff_out);
     GPN_LAUNCH_CHECK("k_ray1");
     return GPN_OK;
   }
 #endif
   using Cfg = RayCfg<NT>;
-  const size_t lds = sizeof(float) * Cfg::LDS_FLOATS;
+  const size_t lds = std::max(sizeof(float) * Cfg::LDS_FLOATS, lds_ff);
   int rc = set_lds_limit(reinterpret_cast<const void*>(k_ray_attn<NT, SPL>), lds);
   if (rc) return rc;
   const int grid = persistent_grid(((long long)R + Cfg::RPW - 1) / Cfg::RPW);
   GpnStageTimer timer_k_ray_attn_(GPN_ST_RAY_ATTN, (hipStream_t)stream);
   hipLaunchKernelGGL((k_ray_attn<NT, SPL>), dim3(grid), dim3(Cfg::THREADS), lds, stream, *L, x_in, R, S,
-                     x_out, abar, abar_ld, weights);
+                     x_out, abar, abar_ld, weights, ff_out);
   GPN_LAUNCH_CHECK("k_ray_attn");
   return GPN_OK;
 }
 
 template <int NT>
 static int launch_ray_attn(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,
-                           float* abar, int abar_ld, float* weights, int precision, hipStream_t stream) {
+                           float* abar, int abar_ld, float* weights, int precision, hipStream_t stream,
+                           float* ff_out) {
   if (precision == GPN_PREC_BF16X3)
-    return launch_ray_attn_p<NT, true>(L, x_in, R, S, x_out, abar, abar_ld, weights, stream);
-  return launch_ray_attn_p<NT, false>(L, x_in, R, S, x_out, abar, abar_ld, weights, stream);
+    return launch_ray_attn_p<NT, true>(L, x_in, R, S, x_out, abar, abar_ld, weights, stream, ff_out);
+  return launch_ray_attn_p<NT, false>(L, x_in, R, S, x_out, abar, abar_ld, weights, stream, ff_out);
 }
 
-extern "C" int gpn_ray_attn(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,
-                            float* abar, int abar_ld, float* weights, int precision,
-                            gpn_stream_t stream) {
+static int ray_attn_launch(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,
+                           float* abar, int abar_ld, float* weights, int precision,
+                           gpn_stream_t stream, float* ff_out) {
   GPN_REQUIRE_PREC(precision, "gpn_ray_attn");
   if (R == 0) return GPN_OK;  // empty batch (pointers may be null)
   GPN_REQUIRE(L && x_in && x_out, "gpn_ray_attn: null pointer");
@@ -2937,18 +3120,26 @@ extern "C" int gpn_ray_attn(const gpn_ray_layer_t* L, const float* x_in, int R, 
               "gpn_ray_attn: samples per ray must be in [1,%d] (got %d)", GPN_MAX_SAMPLES, S);
   GPN_REQUIRE(aligned16(x_in) && aligned16(x_out), "gpn_ray_attn: tensors must be 16-byte aligned");
   GPN_REQUIRE(!abar || abar_ld >= 4, "gpn_ray_attn: abar_ld must be >= 4 (got %d)", abar_ld);
+  GPN_REQUIRE(ff_out == nullptr || (L->ff1.w && L->ff2.w && L->ff_norm_w && L->ff_norm_b),
+              "gpn_ray_attn: fused feed-forward without its weights");
   GPN_REQUIRE_INT_RANGE(R, S, 1, "gpn_ray_attn");
   hipStream_t st = (hipStream_t)stream;
   switch ((S + 15) / 16) {
-    case 1: return launch_ray_attn<1>(L, x_in, R, S, x_out, abar, abar_ld, weights, precision, st);
-    case 2: return launch_ray_attn<2>(L, x_in, R, S, x_out, abar, abar_ld, weights, precision, st);
-    case 3: return launch_ray_attn<3>(L, x_in, R, S, x_out, abar, abar_ld, weights, precision, st);
-    case 4: return launch_ray_attn<4>(L, x_in, R, S, x_out, abar, abar_ld, weights, precision, st);
-    case 5: return launch_ray_attn<5>(L, x_in, R, S, x_out, abar, abar_ld, weights, precision, st);
-    case 6: return launch_ray_attn<6>(L, x_in, R, S, x_out, abar, abar_ld, weights, precision, st);
-    case 7: return launch_ray_attn<7>(L, x_in, R, S, x_out, abar, abar_ld, weights, precision, st);
-    default: return launch_ray_attn<8>(L, x_in, R, S, x_out, abar, abar_ld, weights, precision, st);
+    case 1: return launch_ray_attn<1>(L, x_in, R, S, x_out, abar, abar_ld, weights, precision, st, ff_out);
+    case 2: return launch_ray_attn<2>(L, x_in, R, S, x_out, abar, abar_ld, weights, precision, st, ff_out);
+    case 3: return launch_ray_attn<3>(L, x_in, R, S, x_out, abar, abar_ld, weights, precision, st, ff_out);
+    case 4: return launch_ray_attn<4>(L, x_in, R, S, x_out, abar, abar_ld, weights, precision, st, ff_out);
+    case 5: return launch_ray_attn<5>(L, x_in, R, S, x_out, abar, abar_ld, weights, precision, st, ff_out);
+    case 6: return launch_ray_attn<6>(L, x_in, R, S, x_out, abar, abar_ld, weights, precision, st, ff_out);
+    case 7: return launch_ray_attn<7>(L, x_in, R, S, x_out, abar, abar_ld, weights, precision, st, ff_out);
+    default: return launch_ray_attn<8>(L, x_in, R, S, x_out, abar, abar_ld, weights, precision, st, ff_out);
   }
+}
+
+extern "C" int gpn_ray_attn(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,
+                            float* abar, int abar_ld, float* weights, int precision,
+                            gpn_stream_t stream) {
+  return ray_attn_launch(L, x_in, R, S, x_out, abar, abar_ld, weights, precision, stream, nullptr);
 }
 
 extern "C" int gpn_sem_aggregate(const gpn_sem_args_t* a, gpn_stream_t stream) {
@@ -3111,6 +3302,7 @@ static int gnt_forward_impl(const gpn_gnt_weights_t* W, const gpn_project_args_t
       (rc = gpn_rgbfeat(&W->rgbfeat0, &W->rgbfeat2, rgb_feat, (int)N, V, 3 + W->in_feat_ch, rgb_feat_ld,
                         mask, feat, q, prec, stream)))
     return rc;
+  const bool fuse_qp = GPN_FUSE_VIEW_FF && GPN_FUSE_VIEW_QP;  // the q MLP as a third phase of the view launch
   for (int l = 0; l < D; ++l) {
     // side outputs for the semantic aggregation, interleaved over the layers
     float* hd = sem ? reinterpret_cast<float*>(ws + L.hidden) + l * 8 : nullptr;
@@ -3118,13 +3310,22 @@ static int gnt_forward_impl(const gpn_gnt_weights_t* W, const gpn_project_args_t
     float* ab = sem ? reinterpret_cast<float*>(ws + L.abar) + l * 4 : nullptr;
     const gpn_view_layer_t* vl = &W->view[l];
     const gpn_ray_layer_t* rl = &W->ray[l];
-    if ((rc = view_attn_launch(vl, q, feat, rdp, va_layout, mask, perm, (int)N, V, q, hd, D * 8, st, D * C64, prec, stream)))
+    // the view stage's feed-forward block runs as the second phase of the attention launch
+    if ((rc = view_attn_launch(vl, q, feat, rdp, va_layout, mask, perm, (int)N, V, q, hd, D * 8, st, D * C64, prec, stream,
+                               GPN_FUSE_VIEW_FF ? q : nullptr, &W->qfc0[l], &W->qfc2[l], emb, emb_ray, S,
+                               fuse_qp && l % 2 == 0 ? q : nullptr)))
       return rc;
-    if ((rc = gpn_ff(vl->ff_norm_w, vl->ff_norm_b, &vl->ff1, &vl->ff2, q, (int)N, q, prec, stream))) return rc;
-    if (l % 2 == 0)
+    if (!GPN_FUSE_VIEW_FF &&
+        (rc = gpn_ff(vl->ff_norm_w, vl->ff_norm_b, &vl->ff1, &vl->ff2, q, (int)N, q, prec, stream)))
+      return rc;
+    if (l % 2 == 0 && !fuse_qp)
       if ((rc = gpn_qpos(&W->qfc0[l], &W->qfc2[l], q, emb, emb_ray, (int)N, S, q, prec, stream))) return rc;
-    if ((rc = gpn_ray_attn(rl, q, R, S, q, ab, D * 4, l == D - 1 ? wts : nullptr, prec, stream))) return rc;
-    if ((rc = gpn_ff(rl->ff_norm_w, rl->ff_norm_b, &rl->ff1, &rl->ff2, q, (int)N, q, prec, stream))) return rc;
+    if ((rc = ray_attn_launch(rl, q, R, S, q, ab, D * 4, l == D - 1 ? wts : nullptr, prec, stream,
+                              GPN_FUSE_RAY_FF ? q : nullptr)))
+      return rc;
+    if (!GPN_FUSE_RAY_FF &&
+        (rc = gpn_ff(rl->ff_norm_w, rl->ff_norm_b, &rl->ff1, &rl->ff2, q, (int)N, q, prec, stream)))
+      return rc;
   }
   if (sem) {
     sem->R = R, sem->S = S, sem->V = V, sem->depth = D;

@@ -100,6 +100,10 @@ FF_FLOPS_PER_POINT = 2 * 2 * 64 * 256  # fc1 + fc2 of one FeedForward (SURVEY 8(
 # fp32 (same folded products, one fp32 MFMA flop per algorithmic flop): 11392 + 64 per pair, 17408 per point.
 VIEW_EXEC_FLOPS_PER_PAIR = {"bf16x3": 3 * 11392 + 64, "fp32": 11392 + 64}
 VIEW_EXEC_FLOPS_PER_POINT = {"bf16x3": 3 * 17408, "fp32": 17408}
+# the same as ALGORITHMIC flops of the kernel (one flop per fp32 product, whatever the MFMA type)
+VIEW_ALG_FLOPS_PER_PAIR = 11392 + 64
+VIEW_ALG_FLOPS_PER_POINT = 17408
+QPOS_FLOPS_PER_POINT = 2 * (192 * 64 + 64 * 64)  # q MLP on [q | emb_pt | emb_ray] (190 of the 192 inputs are real)
 
 
 def mfma_peak(precision):
@@ -308,7 +312,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    CANDIDATES = ("view_attn", "ff")  # the two candidates for the dominant kernel
+    CANDIDATES = ("view_attn", "ray_attn")  # the two launches of a layer: the candidates for the dominant kernel
 
     def timed(step, precision, steps, warmup, stages):
         """W warm-up steps, then K steps between fences; max over ranks.  The launches of `stages` (the
@@ -343,72 +347,76 @@ def main():
     def rooflines(precision, tm, dt, steps, samples, vstat, cal, dom_stage):
         """roofline of the dominant kernel of this mode + the whole-path MFMA figure.  `tm`: the event
         times of the dominant kernel inside the timed steps; the other candidate is priced from `cal`, the
-        instrumented step that ran before the timed region (marked `timing_source`)."""
+        instrumented step that ran before the timed region (marked `timing_source`).
+
+        The two candidates are the two launches of a layer: k_view_attn = view
+        attention + the stage's feed-forward block (+ the q MLP on even layers) as phases of ONE launch,
+        k_ray1 / k_ray_attn = ray attention + feed-forward block.  Algorithmic flops = one flop per fp32
+        product the kernel's algorithm needs (folded weight products, computed pairs only); algorithmic
+        bytes = every input / output row once per phase."""
         class _Both:  # per-stage totals: in-step events for the dominant stage, the calibration step otherwise
             ms = {k: (tm.ms[k] if k == dom_stage else cal.ms[k] * steps) for k in CANDIDATES}
             launches = {k: (tm.launches[k] if k == dom_stage else cal.launches[k] * steps) for k in CANDIDATES}
         tm = _Both
         pts_per_launch = CHUNK * sum(samples) / float(len(samples))
+        s_mean = sum(samples) / float(len(samples))
         live = vstat["computed_pair_fraction"]
         peak, peak_note = mfma_peak(precision)
+        mult = 3 if precision == "bf16x3" else 1  # MFMA flops issued per algorithmic flop
         blocks = {}
-        # ---- k_view_attn against the HBM roofline (its bound in bf16x3 mode)
+        # ---- the view launch: attention (HBM-bound in bf16x3) + feed-forward + q MLP on every second layer
         n_va = max(1, tm.launches["view_attn"])
         va_ms = max(tm.ms["view_attn"] / n_va, 1e-9)
-        # per computed (point, view) pair: feature row 256 B + ray_diff 16 B; per visible pair: the 8 hidden
-        # values of attn_fc 32 B; per point: q in 256 + q out 256 + order / visibility words 8
-        # (+ 256 of softmax statistics while that side output exists: see VIEW_STATS_BYTES)
+        # attention phase, per computed (point, view) pair: feature row 256 B + ray_diff 16 B; per visible pair:
+        # the 8 hidden values of attn_fc 32 B; per point: q in 256 + q out 256 + order / visibility words 8
+        # (+ 256 of softmax statistics: VIEW_STATS_BYTES); feed-forward phase: q in + out 512; q MLP phase
+        # (half of the launches): q in + out + the point's encoding 768
         alg_bytes = (VIEWS * live * (256 + 16) + VIEWS * vstat["visible_pair_fraction"] * 32 +
-                     256 + 256 + VIEW_STATS_BYTES + 8) * pts_per_launch
+                     256 + 256 + VIEW_STATS_BYTES + 8 + 512 + 0.5 * 768) * pts_per_launch
         traffic, tsrc = pmc_traffic("k_view_attn" if precision == "bf16x3" else "k_view_attn_fp32")
-        va_flops = view_attn_flops_per_point(VIEWS) * pts_per_launch
-        ex_flops = (VIEWS * live * VIEW_EXEC_FLOPS_PER_PAIR[precision] +
-                    VIEW_EXEC_FLOPS_PER_POINT[precision]) * pts_per_launch
-        blocks["k_view_attn"] = {
-            "hbm": {"bound": "hbm", "kernel": "k_view_attn", "achieved": alg_bytes / (va_ms * 1e-3) / 1e9,
-                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_bytes / (va_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                    "traffic": traffic, "traffic_source": ("%s (rocprofv3 PMC passes of this command; NOT measured "
-                                                           "in this run)" % tsrc) if tsrc else None,
-                    "launches": tm.launches["view_attn"], "mean_launch_ms": va_ms,
-                    "algorithmic_bytes_per_launch": alg_bytes,
-                    "traffic_GBps": (traffic / (va_ms * 1e-3) / 1e9) if traffic else None,
-                    "access_shape_ceiling_GBps": RANDOM_ROW_RW_CEILING_GBPS},
-            "mfma": {"bound": "mfma", "kernel": "k_view_attn", "achieved": va_flops / (va_ms * 1e-3) / 1e12,
-                     "peak": peak, "unit": "TFLOP/s", "frac": va_flops / (va_ms * 1e-3) / 1e12 / peak,
-                     "traffic": traffic, "peak_note": peak_note, "launches": tm.launches["view_attn"],
-                     "mean_launch_ms": va_ms, "algorithmic_flops_per_launch": va_flops,
-                     "executed_mfma_TFLOPs": ex_flops / (va_ms * 1e-3) / 1e12},
+        va_alg = (VIEWS * live * VIEW_ALG_FLOPS_PER_PAIR + VIEW_ALG_FLOPS_PER_POINT + FF_FLOPS_PER_POINT +
+                  0.5 * QPOS_FLOPS_PER_POINT) * pts_per_launch
+        va_ref = (view_attn_flops_per_point(VIEWS) + FF_FLOPS_PER_POINT + 0.5 * 32512) * pts_per_launch
+        va_common = {"kernel": "k_view_attn (attention + feed-forward + q MLP phases)", "launches": tm.launches["view_attn"],
+                     "mean_launch_ms": va_ms, "traffic": traffic,
+                     "traffic_source": ("%s (rocprofv3 PMC passes of this command; NOT measured in this run)" % tsrc)
+                     if tsrc else None}
+        blocks["view_attn"] = {
+            "hbm": dict(va_common, bound="hbm", achieved=alg_bytes / (va_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBPS,
+                        unit="GB/s", frac=alg_bytes / (va_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                        algorithmic_bytes_per_launch=alg_bytes,
+                        traffic_GBps=(traffic / (va_ms * 1e-3) / 1e9) if traffic else None),
+            "mfma": dict(va_common, bound="mfma", achieved=va_alg / (va_ms * 1e-3) / 1e12, peak=peak, unit="TFLOP/s",
+                         frac=va_alg / (va_ms * 1e-3) / 1e12 / peak, peak_note=peak_note,
+                         algorithmic_flops_per_launch=va_alg, issued_mfma_TFLOPs=mult * va_alg / (va_ms * 1e-3) / 1e12,
+                         reference_algorithm_TFLOPs=va_ref / (va_ms * 1e-3) / 1e12),
             "step_share": tm.ms["view_attn"] / steps / (1e3 * dt / steps)}
-        # ---- k_ff against the MFMA roofline
-        n_ff = max(1, tm.launches["ff"])
-        ff_ms = max(tm.ms["ff"] / n_ff, 1e-9)
-        ff_flops = FF_FLOPS_PER_POINT * pts_per_launch
-        ftraffic, fsrc = pmc_traffic("k_ff" if precision == "bf16x3" else "k_ff_fp32")
-        blocks["k_ff"] = {
-            "mfma": {"bound": "mfma", "kernel": "k_ff", "achieved": ff_flops / (ff_ms * 1e-3) / 1e12, "peak": peak,
-                     "unit": "TFLOP/s", "frac": ff_flops / (ff_ms * 1e-3) / 1e12 / peak, "traffic": ftraffic,
-                     "traffic_source": ("%s (rocprofv3 PMC passes of this command; NOT measured in this run)" % fsrc)
-                     if fsrc else None,
-                     "peak_note": peak_note, "launches": tm.launches["ff"], "mean_launch_ms": ff_ms,
-                     "algorithmic_flops_per_launch": ff_flops},
-            "step_share": tm.ms["ff"] / steps / (1e3 * dt / steps)}
-        # dominant = larger share of the step; each kernel priced against the roofline that bounds it in
-        # this mode (bf16x3: k_view_attn is HBM-bound, DESIGN.md section 6; fp32: both are MFMA-bound)
-        dom = "k_" + dom_stage
-        if dom == "k_view_attn":
-            main_ = dict(blocks[dom]["hbm" if precision == "bf16x3" else "mfma"])
-            if precision == "bf16x3":
-                main_["mfma"] = blocks[dom]["mfma"]
-            else:
-                main_["hbm"] = blocks[dom]["hbm"]
+        # ---- the ray launch: attention over the samples of a ray + feed-forward
+        n_ra = max(1, tm.launches["ray_attn"])
+        ra_ms = max(tm.ms["ray_attn"] / n_ra, 1e-9)
+        ra_alg = (4 * 8192 + 256 * s_mean + FF_FLOPS_PER_POINT) * pts_per_launch
+        ra_bytes = (256 + 256 + 16 + 512) * pts_per_launch  # x in / out, mean attention row 16; feed-forward 512
+        rtraffic = None
+        blocks["ray_attn"] = {
+            "mfma": {"bound": "mfma", "kernel": "k_ray1 / k_ray_attn (attention + feed-forward phases)",
+                     "achieved": ra_alg / (ra_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                     "frac": ra_alg / (ra_ms * 1e-3) / 1e12 / peak, "peak_note": peak_note, "traffic": rtraffic,
+                     "launches": tm.launches["ray_attn"], "mean_launch_ms": ra_ms,
+                     "algorithmic_flops_per_launch": ra_alg, "algorithmic_bytes_per_launch": ra_bytes,
+                     "issued_mfma_TFLOPs": mult * ra_alg / (ra_ms * 1e-3) / 1e12},
+            "step_share": tm.ms["ray_attn"] / steps / (1e3 * dt / steps)}
+        # dominant = larger share of the step; priced against the roofline that bounds its largest phase in
+        # this mode (bf16x3: the attention phase of k_view_attn is HBM-bound, DESIGN.md section 6; fp32: MFMA)
+        if dom_stage == "view_attn":
+            main_ = dict(blocks["view_attn"]["hbm" if precision == "bf16x3" else "mfma"])
+            main_["mfma" if precision == "bf16x3" else "hbm"] = blocks["view_attn"]["mfma" if precision == "bf16x3" else "hbm"]
         else:
-            main_ = dict(blocks[dom]["mfma"])
-        main_["step_share"] = blocks[dom]["step_share"]
+            main_ = dict(blocks["ray_attn"]["mfma"])
+        main_["step_share"] = blocks[dom_stage]["step_share"]
         main_["timing_source"] = "HIP events around every launch of this kernel inside the timed steps"
         main_["visibility"] = vstat
-        other = "k_ff" if dom == "k_view_attn" else "k_view_attn"
-        main_["second_kernel"] = dict(blocks[other]["mfma"] if (other == "k_ff" or precision == "fp32")
-                                      else blocks[other]["hbm"], step_share=blocks[other]["step_share"],
+        other = "ray_attn" if dom_stage == "view_attn" else "view_attn"
+        main_["second_kernel"] = dict(blocks[other]["mfma"], step_share=blocks[other]["step_share"],
                                       timing_source="HIP events in one instrumented step before the timed region "
                                                     "(scaled to the timed steps)")
         f_ref = f_ref_per_ray(VIEWS, samples) * CHUNK * world

@@ -42,6 +42,9 @@
 #define VA_SLOT_BYTES (4096 + 256)  // one (tile, view) pair: 16 feature rows + 64 ray_diff floats
 #define VA_DMA_OPS 5
 // cache policy of the feature-row DMA: read once per launch -> non-temporal (measured -5 %)
+#ifndef RAY_FF_MAXNT
+#define RAY_FF_MAXNT 4  // largest NT (16-sample tiles per ray) whose ray kernel takes the feed-forward phase
+#endif
 #ifndef GPN_FUSE_VIEW_QP
 #define GPN_FUSE_VIEW_QP 1  // ... and k_qpos of the even layers as its third phase
 #endif
@@ -2160,6 +2163,7 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
   }
   RA_MARK(4);
   RA_END();
+  if constexpr (NT <= RAY_FF_MAXNT)
   if (ff_out != nullptr) {  // (wave-uniform: a kernel argument)
     const int ngrp = (R + RPW - 1) / RPW;
     const long long nu = (int)blockIdx.x < ngrp ? (ngrp - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
@@ -3065,7 +3069,17 @@ extern "C" int gpn_qpos(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const 
 
 template <int NT, bool SPL>
 static int launch_ray_attn_p(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,
-                             float* abar, int abar_ld, float* weights, hipStream_t stream, float* ff_out) {
+                             float* abar, int abar_ld, float* weights, hipStream_t stream, float* ff_out_req) {
+  // S > 64: k_ray_attn<5..8> has no registers to spare (the extra phase costs spills: measured on the
+  // 96 + 32-sample stress shape, 154 K vs 152 K rays/s in fp32): the feed-forward block stays a launch of
+  // its own there
+  float* ff_out = NT <= RAY_FF_MAXNT ? ff_out_req : nullptr;
+  if (ff_out_req != nullptr && ff_out == nullptr) {
+    int rc0 = launch_ray_attn_p<NT, SPL>(L, x_in, R, S, x_out, abar, abar_ld, weights, stream, nullptr);
+    if (rc0) return rc0;
+    return gpn_ff(L->ff_norm_w, L->ff_norm_b, &L->ff1, &L->ff2, x_out, R * S, ff_out_req,
+                  SPL ? GPN_PREC_BF16X3 : GPN_PREC_FP32, (gpn_stream_t)stream);
+  }
   // (ff_out: the feed-forward phase re-stages LDS with its own weights: the launch needs the larger image)
   const size_t lds_ff = ff_out ? sizeof(float) * ff_lds_floats(SPL) : 0;
 #if GPN_RAY1

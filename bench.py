@@ -396,7 +396,9 @@ def main():
         ra_ms = max(tm.ms["ray_attn"] / n_ra, 1e-9)
         ra_alg = (4 * 8192 + 256 * s_mean + FF_FLOPS_PER_POINT) * pts_per_launch
         ra_bytes = (256 + 256 + 16 + 512) * pts_per_launch  # x in / out, mean attention row 16; feed-forward 512
-        rtraffic = None
+        sfx = "" if precision == "bf16x3" else "_fp32"
+        rt = [pmc_traffic(k + sfx)[0] for k in ("k_ray1_s48", "k_ray_attn_s64")]  # the two passes of a step
+        rtraffic = (sum(rt) / len(rt)) if all(t is not None for t in rt) and len(samples) == 2 else None
         blocks["ray_attn"] = {
             "mfma": {"bound": "mfma", "kernel": "k_ray1 / k_ray_attn (attention + feed-forward phases)",
                      "achieved": ra_alg / (ra_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",

@@ -360,7 +360,11 @@ int gpn_gnt_forward_static(const gpn_gnt_weights_t* W, const float* rgb_feat, in
  * events, returns per-stage summed milliseconds and launch counts (arrays of GPN_NSTAGES) and
  * releases the pool.  One session per process at a time (a second gpn_timing_begin fails until the
  * first session has ended); the pool itself is guarded by a mutex, so launches from other threads
- * while a session is open are safe (they are recorded if their stage is selected). */
+ * while a session is open are safe (they are recorded if their stage is selected).
+ * A stage is a LAUNCH: inside gpn_gnt_forward / gpn_render_pass the feed-forward blocks and the q MLP run as
+ * later phases of the attention launches and are counted under GPN_ST_VIEW_ATTN /
+ * GPN_ST_RAY_ATTN; GPN_ST_FF / GPN_ST_QPOS see the stand-alone gpn_ff / gpn_qpos calls (and the
+ * feed-forward launches of passes with more than 64 samples per ray). */
 enum {
   GPN_ST_SAMPLE = 0, GPN_ST_PROJECT, GPN_ST_PROJECT_DEEP, GPN_ST_POSENC, GPN_ST_RGBFEAT,
   GPN_ST_VIEW_ATTN, GPN_ST_FF, GPN_ST_QPOS, GPN_ST_RAY_ATTN, GPN_ST_SEM, GPN_ST_HEADS,

@@ -1034,6 +1034,25 @@ __device__ __forceinline__ void qp_run(const QpLds& L, const float* q_in, const 
   }
 }
 
+// second phase of an attention kernel (ff_out != nullptr): the layer's feed-forward block on the tiles this
+// workgroup has just written, after re-staging LDS with the FF weights
+template <bool SPL, int TPB, class PT>
+__device__ __forceinline__ void ff_phase(const float* __restrict__ norm_w, const float* __restrict__ norm_b,
+                                         const gpn_linear_t& fc1, const gpn_linear_t& fc2, const float* x, float* ff_out,
+                                         long long nu, int tid, PT&& pt) {
+  const int lane = tid & 63;
+  const FfLds F = ff_lds<SPL>();
+  f4 xpre[FF_NTL][4];
+  // this wave's own stores of x are in program order before these loads
+  if constexpr (SPL) ff_prefetch(xpre, x, 0, lane, pt);
+  FfStager<SPL, TPB> st;
+  st.load(norm_w, norm_b, fc1, fc2, tid);  // in flight across the barrier
+  __syncthreads();  // every wave is done with the attention weights / keys / values in LDS
+  st.store(F, tid);
+  __syncthreads();
+  ff_run<SPL>(F, xpre, x, ff_out, nu, lane, pt);
+}
+
 // third phase of k_view_attn on even layers (qp_out != nullptr): q = q_fcs[l](cat(q, emb_pt, emb_ray)) on the
 // same tiles, LDS re-staged once more
 template <bool SPL, int TPB, class PT>
@@ -1836,25 +1855,6 @@ struct FfRayPt {
     n = (long long)(ray < R ? ray : R - 1) * S + (s < S ? s : S - 1);
   }
 };
-// second phase of a ray kernel (ff_out != nullptr): the layer's feed-forward block on the tiles this
-// workgroup has just written, after re-staging LDS with the FF weights (see k_view_attn)
-template <bool SPL, int TPB, class PT>
-__device__ __forceinline__ void ff_phase(const float* __restrict__ norm_w, const float* __restrict__ norm_b,
-                                         const gpn_linear_t& fc1, const gpn_linear_t& fc2, const float* x, float* ff_out,
-                                         long long nu, int tid, PT&& pt) {
-  const int lane = tid & 63;
-  const FfLds F = ff_lds<SPL>();
-  f4 xpre[FF_NTL][4];
-  // this wave's own stores of x are in program order before these loads
-  if constexpr (SPL) ff_prefetch(xpre, x, 0, lane, pt);
-  FfStager<SPL, TPB> st;
-  st.load(norm_w, norm_b, fc1, fc2, tid);  // in flight across the barrier
-  __syncthreads();  // every wave is done with the attention weights / keys / values in LDS
-  st.store(F, tid);
-  __syncthreads();
-  ff_run<SPL>(F, xpre, x, ff_out, nu, lane, pt);
-}
-
 // ------------------------------------------------------------------------------------ ray attention
 #ifndef GPN_RAY1
 #define GPN_RAY1 1  // S <= 48: k_ray1 (one wave per ray, keys / values in registers); 0: k_ray_attn for every S

@@ -740,6 +740,65 @@ def test_gnt_forward_edge_shapes(dev, net, prec, R, S, V):
     assert all(bool(torch.isfinite(g_).all()) for g_ in got)
 
 
+@pytest.mark.parametrize("R,S,V", [(37, 48, 10), (21, 64, 7), (5, 96, 4)])
+def test_forward_equals_the_chain_of_stage_kernels(dev, net, prec, R, S, V):
+    """Inside gpn_gnt_forward the feed-forward blocks and the q MLP run as later phases of the attention
+    launches, in place, on visibility-ordered tiles (S = 96: the ray stage keeps its
+    own feed-forward launch).  The same network evaluated as a chain of the stand-alone stage kernels of
+    the C-ABI (one launch per block, identity point order, separate output arrays) must give the same
+    bits: the phases share the arithmetic, only the launch structure differs."""
+    from gp_nerf_amd import _lib, synth
+    L = _lib.lib()
+    pc = _lib.precision_code(prec)
+    seed = 7000 + R + S + V
+    hn = lambda k, shape: torch.from_numpy(synth.hash_normal(seed, k, shape))
+    rgb_feat, rd = hn(1, (R, S, V, 35)), hn(3, (R, S, V, 4))
+    mask = (torch.from_numpy(synth.hash_uniform(seed, 4, (R, S, V, 1))) < 0.5).float()
+    mask[0, :3] = 0.0   # samples without a visible view
+    mask[1] = 1.0       # a ray that sees everything
+    ray_d = hn(5, (R, 3)) * 0.3 + torch.tensor([0.0, 0.0, 1.0])
+    z = 1.0 / torch.linspace(1.0 / 0.1, 1.0 / 10.0, S)
+    pts = (z[None, :, None] * ray_d[:, None]).contiguous()
+    cd = to(dev, dict(rgb_feat=rgb_feat, rd=rd, mask=mask, pts=pts, ray_d=ray_d))
+    want, _, _, _ = net.run(cd["rgb_feat"], cd["rd"], cd["mask"], cd["pts"], cd["ray_d"])
+    # ---- the chain
+    N = R * S
+    W = net._weights()
+    st = _lib.stream()
+    e = lambda *s_: torch.empty(s_, device=dev)
+    emb_pt, emb_ray = e(N, 64), e(R, 64)
+    _lib.check(L.gpn_posenc(_lib.ptr(cd["pts"]), _lib.ptr(cd["ray_d"]), R, S, _lib.ptr(emb_pt), _lib.ptr(emb_ray), st),
+               "posenc")
+    mk = cd["mask"].reshape(N, V).contiguous()
+    rdn = cd["rd"].reshape(N, V, 4).contiguous()
+    feat, q = e(N, V, 64), e(N, 64)
+    _lib.check(L.gpn_rgbfeat(C.byref(W.rgbfeat0), C.byref(W.rgbfeat2), _lib.ptr(cd["rgb_feat"]), N, V, 35, 0,
+                             _lib.ptr(mk), _lib.ptr(feat), _lib.ptr(q), pc, st), "rgbfeat")
+    wts = e(R, S)
+    for l in range(net.trans_depth):
+        vl, rl = W.view[l], W.ray[l]
+        q1, q2 = e(N, 64), e(N, 64)
+        _lib.check(L.gpn_view_attn(C.byref(vl), _lib.ptr(q), _lib.ptr(feat), _lib.ptr(rdn), _lib.ptr(mk), None, N, V,
+                                   _lib.ptr(q1), None, 8, None, 64, pc, st), "view")
+        _lib.check(L.gpn_ff(vl.ff_norm_w, vl.ff_norm_b, C.byref(vl.ff1), C.byref(vl.ff2), _lib.ptr(q1), N,
+                            _lib.ptr(q2), pc, st), "ff")
+        if l % 2 == 0:
+            q3 = e(N, 64)
+            _lib.check(L.gpn_qpos(C.byref(W.qfc0[l]), C.byref(W.qfc2[l]), _lib.ptr(q2), _lib.ptr(emb_pt),
+                                  _lib.ptr(emb_ray), N, S, _lib.ptr(q3), pc, st), "qpos")
+            q2 = q3
+        q4, q = e(N, 64), e(N, 64)
+        _lib.check(L.gpn_ray_attn(C.byref(rl), _lib.ptr(q2), R, S, _lib.ptr(q4), None, 4,
+                                  _lib.ptr(wts) if l == net.trans_depth - 1 else None, pc, st), "ray")
+        _lib.check(L.gpn_ff(rl.ff_norm_w, rl.ff_norm_b, C.byref(rl.ff1), C.byref(rl.ff2), _lib.ptr(q4), N,
+                            _lib.ptr(q), pc, st), "ff")
+    got = e(R, 3 + S)
+    _lib.check(L.gpn_heads(C.byref(W), _lib.ptr(q), _lib.ptr(wts), None, None, R, S, _lib.ptr(got), None, None, st),
+               "heads")
+    torch.cuda.synchronize()
+    assert torch.equal(got, want), "fused forward != chain of stage kernels: max diff %g" % float((got - want).abs().max())
+
+
 def test_two_streams_have_their_own_workspace(dev, net):
     """One GNT module driven from two HIP streams at once (the workspace used to be one
     per module): the forwards are enqueued alternately on two streams with different inputs and every

@@ -858,7 +858,10 @@ __device__ __forceinline__ void ff_prefetch(f4 (&xpre)[FF_NTL][4], const float* 
     for (int T = 0; T < 4; ++T) xpre[t][T] = ld4(x_in + (size_t)n * C64 + 16 * T + 4 * (lane >> 4));
   }
 }
-template <bool SPL, class PT>
+// REV: walk the tiles from the last to the first -- as a later phase of an attention kernel the rows a wave
+// wrote LAST are the ones still in L2 (a workgroup writes 200-260 KB per phase, its share of the L2 is 128 KB:
+// re-reading in writing order would miss on every row)
+template <bool SPL, bool REV, class PT>
 __device__ __forceinline__ void ff_run(const FfLds& L, [[maybe_unused]] f4 (&xpre)[FF_NTL][4],
                                        const float* __restrict__ x_in, float* x_out, long long nu, int lane,
                                        PT&& pt) {
@@ -870,7 +873,9 @@ __device__ __forceinline__ void ff_run(const FfLds& L, [[maybe_unused]] f4 (&xpr
     const bf8* w1p = reinterpret_cast<const bf8*>(L.W1) + lane;
     const bf8* w2p = reinterpret_cast<const bf8*>(L.W2) + lane;
     // the input tiles of the next iteration are loaded one iteration ahead (the first ones: ff_prefetch)
-    for (long long u = 0; u < nu; u += NTL) {
+    const long long nur = (nu + NTL - 1) / NTL * NTL;  // whole iterations (`pt` marks tiles >= nu as not real)
+    for (long long uf = 0; uf < nur; uf += NTL) {
+      const long long u = REV ? nur - NTL - uf : uf;
       long long n[NTL];
       bool ok[NTL];
       XS xs[NTL][2];
@@ -881,7 +886,7 @@ __device__ __forceinline__ void ff_run(const FfLds& L, [[maybe_unused]] f4 (&xpr
 #pragma unroll
         for (int T = 0; T < 4; ++T) x[t][T] = xpre[t][T];
       }
-      ff_prefetch(xpre, x_in, u + NTL, lane, pt);
+      ff_prefetch(xpre, x_in, REV ? (u >= NTL ? u - NTL : 0) : u + NTL, lane, pt);
 #pragma unroll
       for (int t = 0; t < NTL; ++t) {
         f4 xn[4];
@@ -918,7 +923,8 @@ __device__ __forceinline__ void ff_run(const FfLds& L, [[maybe_unused]] f4 (&xpr
       }
     }
   } else {
-    for (long long u = 0; u < nu; ++u) {
+    for (long long uf = 0; uf < nu; ++uf) {
+      const long long u = REV ? nu - 1 - uf : uf;
       long long n;
       bool valid;
       pt(u, j, n, valid);
@@ -1044,13 +1050,14 @@ __device__ __forceinline__ void ff_phase(const float* __restrict__ norm_w, const
   const FfLds F = ff_lds<SPL>();
   f4 xpre[FF_NTL][4];
   // this wave's own stores of x are in program order before these loads
-  if constexpr (SPL) ff_prefetch(xpre, x, 0, lane, pt);
+  if constexpr (SPL)  // ff_run<REV> starts at the last iteration
+    ff_prefetch(xpre, x, nu > 0 ? (nu + FF_NTL - 1) / FF_NTL * FF_NTL - FF_NTL : 0, lane, pt);
   FfStager<SPL, TPB> st;
   st.load(norm_w, norm_b, fc1, fc2, tid);  // in flight across the barrier
   __syncthreads();  // every wave is done with the attention weights / keys / values in LDS
   st.store(F, tid);
   __syncthreads();
-  ff_run<SPL>(F, xpre, x, ff_out, nu, lane, pt);
+  ff_run<SPL, true>(F, xpre, x, ff_out, nu, lane, pt);
 }
 
 // third phase of k_view_attn on even layers (qp_out != nullptr): q = q_fcs[l](cat(q, emb_pt, emb_ray)) on the
@@ -1637,7 +1644,7 @@ k_ff(const float* __restrict__ norm_w, const float* __restrict__ norm_b, gpn_lin
   ff_stage<SPL, FF_TPB>(L, norm_w, norm_b, fc1, fc2, tid);
   __syncthreads();
   STAMP(10);
-  ff_run<SPL>(L, xpre, x_in, x_out, nu, lane, pt);
+  ff_run<SPL, false>(L, xpre, x_in, x_out, nu, lane, pt);
   STAMP(11);
   WAVE_T(1);
 }

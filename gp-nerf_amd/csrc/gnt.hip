@@ -2740,40 +2740,59 @@ k_heads_rgb(const float* __restrict__ norm_w, const float* __restrict__ norm_b, 
   }
 }
 
-// sem_feat = ReLU(W pre + b): [R,512] x [512,512]^T on MFMA; one wave per (16 rays, 128 outputs).
+// sem_feat = ReLU(W pre + b): [R,512] x [512,512]^T on fp32 MFMA.  A workgroup takes 64 rays x 128 output
+// columns: wave (rt, ch) = 16 rays x 64 columns, the 128 x 512 weight slab goes through LDS in eight
+// double-buffered 64-wide K chunks loaded by the whole workgroup (the first form read its weight rows
+// straight from L2, one dependent round trip per 16 K: 44 us per launch at R = 4096, latency-bound).
+#define SA_LDW 68
+#define SA_LDS_FLOATS (2 * 128 * SA_LDW)
 __global__ void __launch_bounds__(512)
 k_sem_adaptor(gpn_linear_t fc, const float* __restrict__ pre, int R, float* __restrict__ sem_feat) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
-  const int r0 = blockIdx.x * 16;
-  const int rr = r0 + j;
+  const int rt = wave & 3, ch = wave >> 2;
+  const int c0 = (blockIdx.x & 3) * 128;             // first output column of the workgroup
+  const int rr = (blockIdx.x >> 2) * 64 + rt * 16 + j;
   const bool valid = rr < R;
   const int rc = valid ? rr : R - 1;
+  // slab chunk kc: rows c0 .. c0+127 of W, columns 64 kc .. 64 kc + 63; 2048 float4, four per thread
+  f4 wreg[4];
+  auto slab_load = [&](int kc) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + it * 512, row = idx >> 4, c4 = idx & 15;
+      wreg[it] = ld4(fc.w + (size_t)(c0 + row) * GPN_SEM + 64 * kc + 4 * c4);
+    }
+  };
+  auto slab_store = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + it * 512, row = idx >> 4, c4 = idx & 15;
+      st4(smem + buf * (128 * SA_LDW) + row * SA_LDW + 4 * c4, wreg[it]);
+    }
+  };
+  slab_load(0);
   f4 x[32];
 #pragma unroll
   for (int T = 0; T < 32; ++T) x[T] = ld4(pre + (size_t)rc * GPN_SEM + 16 * T + 4 * g);
-  const float* wp = fc.w + (size_t)j * GPN_SEM + 4 * g;
-  {  // 8 waves x 64 output columns: two waves per SIMD hide the L2 latency of the weight reads
-    const int M0 = wave * 4;
-    f4 y[4];
+  f4 y[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) y[m] = fc.b ? ld4(fc.b + c0 + 64 * ch + 16 * m + 4 * g) : f4_zero();
+  slab_store(0);
+  __syncthreads();
+#pragma unroll
+  for (int kc = 0; kc < 8; ++kc) {
+    if (kc + 1 < 8) slab_load(kc + 1);  // in flight under this chunk's MFMAs
+    lin_T<4, 4>(smem + (kc & 1) * (128 * SA_LDW) + 64 * ch * SA_LDW, SA_LDW, x + 4 * kc, y, lane);
+    if (kc + 1 < 8) {
+      slab_store((kc + 1) & 1);  // (that buffer was last read in chunk kc - 1: every wave is past the barrier since)
+      __syncthreads();
+    }
+  }
+  if (valid) {
 #pragma unroll
     for (int m = 0; m < 4; ++m)
-      y[m] = fc.b ? ld4(fc.b + 16 * (M0 + m) + 4 * g) : f4_zero();
-#pragma unroll
-    for (int T = 0; T < 32; ++T) {
-      f4 w[4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) w[m] = ld4(wp + (size_t)(16 * (M0 + m)) * GPN_SEM + 16 * T);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) y[m] = mfma16(w[m][r], x[T][r], y[m]);
-    }
-    if (valid) {
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-        st4(sem_feat + (size_t)rr * GPN_SEM + 16 * (M0 + m) + 4 * g, f4_relu(y[m]));
-    }
+      st4(sem_feat + (size_t)rr * GPN_SEM + c0 + 64 * ch + 16 * m + 4 * g, f4_relu(y[m]));
   }
 }
 
@@ -3222,8 +3241,10 @@ extern "C" int gpn_heads(const gpn_gnt_weights_t* W, const float* q, const float
     GPN_REQUIRE(sem_feat, "gpn_heads: pre given without sem_feat");
     REQ_LIN(W->sem_adaptor, "gpn_heads.sem_adaptor");
     GPN_REQUIRE(aligned16(pre) && aligned16(sem_feat), "gpn_heads: sem tensors must be aligned");
+    int rc_a = set_lds_limit(reinterpret_cast<const void*>(k_sem_adaptor), sizeof(float) * SA_LDS_FLOATS);
+    if (rc_a) return rc_a;
     GpnStageTimer timer_k_sem_adaptor_(GPN_ST_HEADS, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_sem_adaptor, dim3(gpn_ceil_div(R, 16)), dim3(512), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_sem_adaptor, dim3(4 * gpn_ceil_div(R, 64)), dim3(512), sizeof(float) * SA_LDS_FLOATS, (hipStream_t)stream,
                        W->sem_adaptor, pre, R, sem_feat);
     GPN_LAUNCH_CHECK("k_sem_adaptor");
   }

@@ -5,6 +5,6 @@ for lib in "$@"; do
   python - $lib <<'PY'
 import json,sys
 l=[x for x in open("/tmp/ab.log") if x.startswith("{")][-1]; d=json.loads(l)
-print("%-44s ms/step %.3f  %s" % (sys.argv[1].split("/")[-1], d["ms_per_step"], {k: v for k, v in d["stage_ms_one_step"].items() if v > 0.2}), flush=True)
+print("%-44s ms/step %.3f  %s" % (sys.argv[1].split("/")[-1], d["ms_per_step"], {k: v for k, v in d["stage_ms_one_step"].items() if v > 0.1}), flush=True)
 PY
 done

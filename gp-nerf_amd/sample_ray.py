@@ -42,58 +42,44 @@ def _dev(t, device):
 
 
 class RaySamplerSingleImage(object):
+    # per-pixel tensors of the query image: attribute name -> channels of a flattened row
+    _PIXEL_FIELDS = (("rgb", 3), ("labels", 1), ("true_depth", 1), ("depth_mask", 1))
+
     def __init__(self, data, device, resize_factor=1, render_stride=1):
+        """`data`: one item of a reference dataset (attributes as reference sample_ray.py:39-93)."""
         super().__init__()
-        self.render_stride = render_stride
-        self.rgb = data["rgb"] if "rgb" in data.keys() else None
-        self.labels = data["labels"] if "labels" in data.keys() else None
-        self.camera = data["camera"]
-        self.rgb_path = data["rgb_path"]
-        self.true_depth = data["true_depth"]
-        self.depth_mask = data["depth_mask"]
-        self.depth_range = data["depth_range"]
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("RaySamplerSingleImage generates rays on a HIP device (got %s); there "
                                "is no CPU fallback" % (self.device,))
-        if self.camera.shape[-1] == 34:
-            W, H, self.intrinsics, self.c2w_mat = parse_camera_ray(self.camera)
-        else:
-            W, H, self.intrinsics, self.c2w_mat = parse_camera(self.camera)
+        self.render_stride = render_stride
+        # optional entries default to None; the mandatory ones raise KeyError as in the reference
+        for name in ("rgb", "labels", "src_rgbs", "src_cameras", "src_labels"):
+            setattr(self, name, data.get(name))
+        for name in ("camera", "rgb_path", "true_depth", "depth_mask", "depth_range"):
+            setattr(self, name, data[name])
+        parse = parse_camera_ray if self.camera.shape[-1] == 34 else parse_camera
+        widths, heights, self.intrinsics, self.c2w_mat = parse(self.camera)
         self.batch_size = len(self.camera)
         if self.batch_size != 1:
             raise ValueError("one query image per sampler (the render path asserts batch size 1, "
                              "reference projection.py:97-101)")
-
-        self.H = int(H[0])
-        self.W = int(W[0])
-
-        # half-resolution output (reference :58-80)
-        if resize_factor != 1:
-            self.W = int(self.W * resize_factor)
-            self.H = int(self.H * resize_factor)
+        self.H, self.W = int(heights[0]), int(widths[0])
+        if resize_factor != 1:  # resized output (reference :58-80): image size, intrinsics and pixel tensors
+            self.H, self.W = int(self.H * resize_factor), int(self.W * resize_factor)
             self.intrinsics = self.intrinsics.clone()
             self.intrinsics[:, :2, :3] *= resize_factor
-            for name in ("rgb", "labels", "true_depth", "depth_mask"):
+            for name, _ in self._PIXEL_FIELDS:
                 t = getattr(self, name)
                 if t is not None:
                     setattr(self, name, F.interpolate(t.permute(0, 3, 1, 2),
                                                       scale_factor=resize_factor).permute(0, 2, 3, 1))
-
         self.rays_o, self.rays_d = self.get_rays_single_image(self.H, self.W, self.intrinsics,
                                                               self.c2w_mat)
-        if self.rgb is not None:
-            self.rgb = self.rgb.reshape(-1, 3)
-        if self.labels is not None:
-            self.labels = self.labels.reshape(-1, 1)
-        if self.true_depth is not None:
-            self.true_depth = self.true_depth.reshape(-1, 1)
-        if self.depth_mask is not None:
-            self.depth_mask = self.depth_mask.reshape(-1, 1)
-
-        self.src_rgbs = data["src_rgbs"] if "src_rgbs" in data.keys() else None
-        self.src_cameras = data["src_cameras"] if "src_cameras" in data.keys() else None
-        self.src_labels = data["src_labels"] if "src_labels" in data.keys() else None
+        for name, ch in self._PIXEL_FIELDS:  # one row per pixel, in ray order
+            t = getattr(self, name)
+            if t is not None:
+                setattr(self, name, t.reshape(-1, ch))
 
     # -------------------------------------------------------------------------------------------
     def _matrix(self, intrinsics, c2w):

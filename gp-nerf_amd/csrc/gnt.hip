@@ -847,7 +847,7 @@ __device__ __forceinline__ void ff_stage(const FfLds& L, const float* __restrict
 // split mode: the input rows of the wave's tiles u0 .. u0+NTL-1 (the first ones are requested before /
 // while the weights are staged)
 template <class PT>
-__device__ __forceinline__ void ff_prefetch(f4 (&xpre)[FF_NTL][4], const float* __restrict__ x_in, long long u0,
+__device__ __forceinline__ void ff_prefetch(f4 (&xpre)[FF_NTL][4], const float* x_in, long long u0,
                                             int lane, PT&& pt) {
 #pragma unroll
   for (int t = 0; t < FF_NTL; ++t) {
@@ -863,7 +863,7 @@ __device__ __forceinline__ void ff_prefetch(f4 (&xpre)[FF_NTL][4], const float* 
 // re-reading in writing order would miss on every row)
 template <bool SPL, bool REV, class PT>
 __device__ __forceinline__ void ff_run(const FfLds& L, [[maybe_unused]] f4 (&xpre)[FF_NTL][4],
-                                       const float* __restrict__ x_in, float* x_out, long long nu, int lane,
+                                       const float* x_in, float* x_out, long long nu, int lane,
                                        PT&& pt) {
   const int j = lane & 15, g = lane >> 4;
   if constexpr (SPL) {
@@ -1077,9 +1077,9 @@ __device__ __forceinline__ void qp_phase(const gpn_linear_t& fc0, const gpn_line
 
 template <bool SPL, bool FOLD, bool TILED = false>
 __global__ void __launch_bounds__(VA_TPB)
-k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __restrict__ feat,
+k_view_attn(gpn_view_layer_t Lw, const float* q_in, const float* __restrict__ feat,
             const float* __restrict__ ray_diff, const float* __restrict__ mask,
-            const int* __restrict__ perm, long long N, int V, float* __restrict__ q_out,
+            const int* __restrict__ perm, long long N, int V, float* q_out,
             float* __restrict__ hidden, int hidden_ld, float* __restrict__ stats, int stats_ld,
             int layout, float* ff_out, gpn_linear_t qfc0, gpn_linear_t qfc2, const float* __restrict__ emb_pt,
             const float* __restrict__ emb_ray, int S, float* qp_out) {
@@ -1627,7 +1627,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* __restrict__ q_in, const float* __
 template <bool SPL>
 __global__ void __launch_bounds__(FF_TPB)
 k_ff(const float* __restrict__ norm_w, const float* __restrict__ norm_b, gpn_linear_t fc1,
-     gpn_linear_t fc2, const float* __restrict__ x_in, long long N, float* __restrict__ x_out) {
+     gpn_linear_t fc2, const float* x_in, long long N, float* x_out) {
   const FfLds L = ff_lds<SPL>();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   STAMP(8);
@@ -1838,9 +1838,9 @@ k_ff32(const float* __restrict__ norm_w, const float* __restrict__ norm_b, gpn_l
 // ------------------------------------------------------------------------------------ q positional MLP (kernel)
 template <bool SPL>
 __global__ void __launch_bounds__(QP_TPB)
-k_qpos(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ q_in,
+k_qpos(gpn_linear_t fc0, gpn_linear_t fc2, const float* q_in,
        const float* __restrict__ emb_pt, const float* __restrict__ emb_ray, long long N, int S,
-       float* __restrict__ q_out) {
+       float* q_out) {
   const QpLds L = qp_lds<SPL>();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   qp_stage<SPL, QP_TPB>(L, fc0, fc2, tid);
@@ -1890,8 +1890,8 @@ struct RayCfg {
 // a_hi*x_hi + a_mid*x_hi, against B = [x_mid | 0] it yields a_hi*x_mid.
 template <int NT, bool SPL>
 __global__ void __launch_bounds__(RayCfg<NT>::THREADS)
-k_ray_attn(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S,
-           float* __restrict__ x_out, float* __restrict__ abar, int abar_ld,
+k_ray_attn(gpn_ray_layer_t Lw, const float* x_in, int R, int S,
+           float* x_out, float* __restrict__ abar, int abar_ld,
            float* __restrict__ weights, float* ff_out) {
   // S (<= SP) real samples per ray; keys >= S are masked out of the softmax, queries >= S are
   // computed on clamped data and never stored.
@@ -2199,7 +2199,7 @@ constexpr int ray1_lds_floats(bool spl) { return 4 * wimg_floats(spl, 64, 4, LDW
 
 template <int NT, bool SPL>
 __global__ void __launch_bounds__(RAY1_WAVES * 64, RAY1_MINW)
-k_ray1(gpn_ray_layer_t Lw, const float* __restrict__ x_in, int R, int S, float* __restrict__ x_out,
+k_ray1(gpn_ray_layer_t Lw, const float* x_in, int R, int S, float* x_out,
        float* __restrict__ abar, int abar_ld, float* __restrict__ weights, float* ff_out) {
   constexpr int NTHR = RAY1_WAVES * 64;
   float* Wq = smem;

@@ -147,6 +147,10 @@ typedef struct {
 int gpn_project_gather(const gpn_project_args_t* a, gpn_stream_t stream);
 
 /* ------------------------------------------------------------------ GNT (subsystem 2) */
+/* In-place use: the per-point stage kernels (gpn_view_attn q_in / q_out, gpn_ff, gpn_qpos, gpn_ray_attn x_in /
+ * x_out) may be given the SAME array as input and output -- every row is read by the lanes that write it
+ * (a ray's rows by the workgroup that owns the ray, behind a barrier); gpn_gnt_forward runs the whole
+ * layer stack on one [N,C] array this way.  Partially overlapping arrays are not supported. */
 
 typedef struct {
   const float* w; /* [out,in] row-major (nn.Linear.weight) */

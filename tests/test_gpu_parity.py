@@ -782,14 +782,29 @@ def test_forward_equals_the_chain_of_stage_kernels(dev, net, prec, R, S, V):
                                    _lib.ptr(q1), None, 8, None, 64, pc, st), "view")
         _lib.check(L.gpn_ff(vl.ff_norm_w, vl.ff_norm_b, C.byref(vl.ff1), C.byref(vl.ff2), _lib.ptr(q1), N,
                             _lib.ptr(q2), pc, st), "ff")
+        if l == 0:  # the stage kernels may be used in place (include/gpnerf_hip.h): same bits
+            qi = q1.clone()
+            _lib.check(L.gpn_ff(vl.ff_norm_w, vl.ff_norm_b, C.byref(vl.ff1), C.byref(vl.ff2), _lib.ptr(qi), N,
+                                _lib.ptr(qi), pc, st), "ff in place")
+            assert torch.equal(qi, q2), "gpn_ff in place"
         if l % 2 == 0:
             q3 = e(N, 64)
             _lib.check(L.gpn_qpos(C.byref(W.qfc0[l]), C.byref(W.qfc2[l]), _lib.ptr(q2), _lib.ptr(emb_pt),
                                   _lib.ptr(emb_ray), N, S, _lib.ptr(q3), pc, st), "qpos")
+            if l == 0:
+                qi = q2.clone()
+                _lib.check(L.gpn_qpos(C.byref(W.qfc0[l]), C.byref(W.qfc2[l]), _lib.ptr(qi), _lib.ptr(emb_pt),
+                                      _lib.ptr(emb_ray), N, S, _lib.ptr(qi), pc, st), "qpos in place")
+                assert torch.equal(qi, q3), "gpn_qpos in place"
             q2 = q3
         q4, q = e(N, 64), e(N, 64)
         _lib.check(L.gpn_ray_attn(C.byref(rl), _lib.ptr(q2), R, S, _lib.ptr(q4), None, 4,
                                   _lib.ptr(wts) if l == net.trans_depth - 1 else None, pc, st), "ray")
+        if l == 0:
+            qi = q2.clone()
+            _lib.check(L.gpn_ray_attn(C.byref(rl), _lib.ptr(qi), R, S, _lib.ptr(qi), None, 4, None, pc, st),
+                       "ray in place")
+            assert torch.equal(qi, q4), "gpn_ray_attn in place"
         _lib.check(L.gpn_ff(rl.ff_norm_w, rl.ff_norm_b, C.byref(rl.ff1), C.byref(rl.ff2), _lib.ptr(q4), N,
                             _lib.ptr(q), pc, st), "ff")
     got = e(R, 3 + S)

@@ -19,25 +19,34 @@ bf16 MFMAs on split operands, fp32 accumulation, ~2^-16 per product; include/gpn
 1e-4 parity bar (tests/test_gpu_parity.py runs both) and is measured on the same workload under the key
 "bf16x3", with its own roofline blocks.  `--precision bf16x3` swaps the two.
 
-Prints ONE JSON line (rank 0):
+Prints ONE JSON line on stdout (rank 0), at most 4 KB -- the driver reads the tail of stdout -- with one
+pricing per item; everything else (both pricings of every candidate kernel, the stage tables, the full block
+of every leg) goes to stderr and to `bench_detail.json` (`detail_file`):
   roofline      the kernel with the largest share of the step in the headline mode.  fp32: an MFMA-bound
-                kernel -> bound "mfma", achieved = SURVEY.md 8(d) reference-algorithm flops per launch /
-                mean launch time (HIP events inside the timed steps, on the launch stream), peak = fp32
-                matrix peak.  bf16x3: k_view_attn, HBM-bound -> algorithmic bytes per launch / launch time
-                against 8 TB/s; `traffic` = HBM bytes per launch from the committed PMC passes under
-                profiles/ (NOT measured in this run: `traffic_source` says which file).
-  path_mfma     SURVEY.md 8(d) whole-path figure: F_ref (1.806 TFLOP per 4096-ray two-pass step, the
+                kernel -> bound "mfma", achieved = ALGORITHMIC flops per launch (one flop per fp32 product the
+                kernel's algorithm needs: computed pairs only, folded products) / mean launch time (HIP events
+                inside the timed steps, on the launch stream), peak = fp32 matrix peak.  bf16x3: k_view_attn,
+                HBM-bound -> algorithmic bytes per launch / launch time against 8 TB/s; `traffic` = HBM bytes
+                per launch from the committed PMC passes under profiles/ (NOT measured in this run:
+                `traffic_source` says which file).
+  path_vs_reference_flops
+                SURVEY.md 8(d) whole-path figure: F_ref (1.806 TFLOP per 4096-ray two-pass step, the
                 reference algorithm's GEMM-class flops whether or not the kernels execute them) / step
-                time, against the MFMA peak of the mode.
-  legs          the other 8(d) legs on the same scene: single_pass_64 (N_samples=64, N_importance=0: the
+                time, and its ratio to the MFMA peak of the mode.  NOT a roofline fraction: the kernels skip
+                views with zero attention weight exactly and fold weight products, so the ratio exceeds 1 on
+                the sparse rig; legs.dense_visibility is the rig where nothing is skipped.
+  other_modes   the other arithmetic modes on the same workload (rays/s, step time, dominant-kernel fraction).
+  legs          one or two numbers per leg: single_pass_64 (N_samples=64, N_importance=0: the
                 literal "4096 rays x 64 samples x 10 views"), dense_visibility (5 cm / no-yaw rig, near
                 plane 1 m: ~96 % of the (sample, view) pairs visible instead of ~41 %), projector_standalone
                 (Projector.compute with the 512-channel gather materialised, B_proj of SURVEY 8(d)),
                 stress_shape (BASELINE configs[4] on one GPU: 16 views, 1296x968 images, 96 + 32 samples),
                 scannet_eval_view (BASELINE configs[2]: encoders + 76,800 rays + semantic head, seconds per view),
-                chunk_16384 (the headline workload at four times the rays per step: what the per-launch fixed
-                cost takes at the reference's default chunk).
-  cpu_baseline  the CPU oracle (a port of the reference path) on a bounded ray sample.
+                chunk_16384 (the headline workload at four times the rays per step), full image seconds.
+  cpu_baseline  the CPU oracle (a port of the reference path) on a bounded ray sample + max relative error of
+                the GPU result against it.
+  N > 1         rccl_world (an all-reduce of ones over the job's backend: the number of ranks RCCL saw),
+                rank_ms_per_step (every rank's own clock), the collective inside the timed steps.
 """
 import argparse
 import json
@@ -330,6 +339,7 @@ def main():
                 r = step()
             fence()
             dt = time.perf_counter() - t0
+        timed.rank_dt = dt  # this rank's own clock; `dt` below is the maximum over the ranks
         if multi:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -440,8 +450,8 @@ def main():
         vstat = visibility_stats(sc, batch, projector, n_s, n_i, cw)
         roof, path = rooflines(precision, tm, dt, steps, samples, vstat, cal, dom_stage)
         return ret, {"precision": precision, "value": world * CHUNK * steps / dt, "unit": "rays/s",
-                     "ms_per_step": 1e3 * dt / steps, "roofline": roof, "path_mfma": path,
-                     "stage_ms_one_step": table}
+                     "ms_per_step": 1e3 * dt / steps, "rank_ms_per_step": 1e3 * timed.rank_dt / steps,
+                     "roofline": roof, "path_mfma": path, "stage_ms_one_step": table}
 
     two_pass = make_step(scene, rb, N_SAMPLES, N_IMPORTANCE)
     samples2 = [N_SAMPLES, N_SAMPLES + N_IMPORTANCE]
@@ -512,25 +522,163 @@ def main():
                 cpu["max_rel_err_gpu_vs_cpu_" + mode] = err
                 cpu["fine_rays_resampled_" + mode] = resampled
 
+    rccl_world = None
+    if multi:  # proof that the collective backend saw every rank: an all-reduce of ones (+ per-rank step times)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        rccl_world = int(ones.item())
+        mine = torch.tensor([head["rank_ms_per_step"]], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [round(float(t.item()), 4) for t in every]
+    else:
+        rank_ms = None
+
     if rank == 0:
+        detail = {"headline": dict(head, stage_ms_one_step=stages), omode: other, "legs": legs,
+                  "full_image": full_image, "cpu_baseline": cpu}
+        legs_file = write_detail(detail)
         line = {
             "metric": "rays_per_sec", "value": head["value"], "unit": "rays/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if a.precision == "fp32" else "f32 (bf16x3 split-operand MFMA, fp32 accumulate)",
-            "headline_precision": a.precision,
-            "data": "synthetic",
+            "dtype": DTYPES[a.precision], "headline_precision": a.precision, "data": "synthetic",
             "config": {"workload": "replica_640x480_10views render_rays chunk=%d rays/GPU, "
                                    "coarse 48 + importance 16 (48- and 64-sample passes)" % CHUNK,
-                       "precision": a.precision,
                        "rays_per_step_per_gpu": CHUNK, "samples": samples2,
                        "views": VIEWS, "parallelism": "ray-sharded x%d" % world},
-            "roofline": head["roofline"], "path_mfma": head["path_mfma"], "cpu_baseline": cpu,
-            omode: other, "stage_ms_one_step": stages, "legs": legs, "full_image": full_image,
+            "roofline": compact_roofline(head["roofline"]),
+            "path_vs_reference_flops": compact_path(head["path_mfma"], head["roofline"]),
+            "cpu_baseline": compact_cpu(cpu, a.precision),
+            "other_modes": {omode: compact_mode(other)} if other else None,
+            "legs": compact_legs(legs, full_image),
+            "stage_ms_one_step": {k: round(v, 3) for k, v in stages.items()},
+            "detail_file": legs_file,
         }
-        print(json.dumps(line))
+        if multi:
+            line["rccl_world"] = rccl_world
+            line["backend"] = dist.get_backend()
+            line["rank_ms_per_step"] = rank_ms
+            line["collective"] = "all_gather_into_tensor of [rays, %d] fp32 tiles inside every timed step" % tile_w
+        text = json.dumps(round_floats(line))
+        for drop in ("stage_ms_one_step", "legs", "other_modes", "path_vs_reference_flops"):  # never again an unparseable line
+            if len(text) > 4000:
+                line[drop] = "see " + str(legs_file)
+                text = json.dumps(round_floats(line))
+        sys.stdout.flush()
+        print(text, flush=True)
     if multi:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------- the printed line
+DTYPES = {"fp32": "f32", "bf16x3": "f32 (bf16x3 split-operand MFMA, fp32 accumulate)",
+          "bf16": "bf16 (one bf16 MFMA per product, fp32 accumulate; softmax / LayerNorm / residuals fp32)"}
+DETAIL_FILE = "bench_detail.json"
+
+
+def round_floats(x, digits=5):
+    """Floats to `digits` significant figures (the printed line must stay short)."""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x))
+    if isinstance(x, dict):
+        return {k: round_floats(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [round_floats(v, digits) for v in x]
+    return x
+
+
+def write_detail(detail):
+    """Everything that used to ride on the printed line (per-mode roofline blocks with their alternative
+    pricings, the stage tables, the full block of every leg) goes to a file beside bench.py (or the
+    working directory) and to stderr; the printed line keeps one number per item.  -> the file's name."""
+    text = json.dumps(round_floats(detail, 6), indent=1)
+    print(text, file=sys.stderr)
+    for d in (os.path.join(ROOT, "gpurun_out"), ROOT, os.getcwd()):
+        try:
+            if not os.path.isdir(d):
+                continue
+            with open(os.path.join(d, DETAIL_FILE), "w") as f:
+                f.write(text)
+            return os.path.relpath(os.path.join(d, DETAIL_FILE), ROOT)
+        except OSError:
+            continue
+    return None
+
+
+def compact_roofline(r):
+    """The contract's roofline object for the dominant kernel (one pricing: the roof that bounds it)."""
+    keys = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "launches",
+            "mean_launch_ms", "step_share", "timing_source", "algorithmic_flops_per_launch",
+            "algorithmic_bytes_per_launch")
+    out = {k: r[k] for k in keys if r.get(k) is not None}
+    out.setdefault("traffic", None)
+    if out.get("traffic_source"):
+        out["traffic_source"] = out["traffic_source"].split(" (")[0] + " (committed PMC passes, not this run)"
+    out["timing_source"] = "HIP events inside the timed steps"
+    out["computed_pair_fraction"] = r["visibility"]["computed_pair_fraction"]
+    sk = r.get("second_kernel")
+    if sk:
+        out["second_kernel"] = {"kernel": sk["kernel"], "bound": sk["bound"], "frac": sk["frac"],
+                                "mean_launch_ms": sk["mean_launch_ms"], "step_share": sk["step_share"]}
+    return out
+
+
+def compact_path(p, r):
+    """SURVEY 8(d)'s whole-path figure.  NOT a roofline fraction: the numerator is the REFERENCE algorithm's
+    flop count, and the kernels skip views with zero attention weight exactly and use folded weight
+    products, so the ratio to the MFMA peak exceeds 1 on scenes with few visible pairs."""
+    return {"reference_TFLOP_per_step": p["F_ref_TFLOP_per_step"], "reference_TFLOPs_rate": p["achieved_TFLOPs"],
+            "mfma_peak_TFLOPs": p["peak_TFLOPs"], "ratio_to_mfma_peak": p["frac"],
+            "computed_pair_fraction": r["visibility"]["computed_pair_fraction"],
+            "note": "reference-algorithm flops / step time; can exceed 1 (skipped pairs, folded products): "
+                    "not a roofline fraction -- see legs.dense_visibility for the rig where nothing is skipped"}
+
+
+def compact_cpu(cpu, precision):
+    if not cpu:
+        return None
+    out = {k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample")}
+    out["max_rel_err"] = cpu.get("max_rel_err_gpu_vs_cpu_" + precision)
+    out["fine_rays_resampled"] = cpu.get("fine_rays_resampled_" + precision)
+    out["max_rel_err_other_modes"] = {k[len("max_rel_err_gpu_vs_cpu_"):]: v for k, v in cpu.items()
+                                      if k.startswith("max_rel_err_gpu_vs_cpu_") and not k.endswith("_" + precision)}
+    return out
+
+
+def compact_mode(m):
+    """One arithmetic mode on the headline workload: rays/s, step time, the dominant kernel's roofline fraction."""
+    if not m:
+        return None
+    r = m["roofline"]
+    return {"value": m["value"], "ms_per_step": m["ms_per_step"], "roofline_kernel": r["kernel"].split(" (")[0],
+            "roofline_bound": r["bound"], "roofline_frac": r["frac"], "mean_launch_ms": r["mean_launch_ms"]}
+
+
+def compact_legs(legs, full_image):
+    """One or two numbers per leg (rays/s unless the key says otherwise)."""
+    if not legs:
+        return None
+    out = {}
+    for name, leg in legs.items():
+        if name == "projector_standalone":
+            out[name] = {"ms_per_call": leg["ms_per_call"], "hbm_frac": leg["roofline"]["frac"],
+                         "achieved_GBps": leg["roofline"]["achieved"]}
+        elif name == "scannet_eval_view":
+            out[name] = {m: leg[m]["seconds_per_view"] for m in leg if isinstance(leg[m], dict)}
+            out[name]["unit"] = "s/view"
+        elif name == "chunk_16384":
+            out[name] = {m: leg[m]["rays_%d" % (4 * CHUNK)]["value"] for m in leg if isinstance(leg[m], dict)}
+        else:
+            out[name] = {m: leg[m]["value"] for m in leg if isinstance(leg[m], dict)}
+            if name == "dense_visibility":
+                out[name]["fp32_ratio_to_mfma_peak"] = leg["fp32"]["path_mfma"]["frac"]
+                out[name]["fp32_kernel_frac"] = leg["fp32"]["roofline"]["frac"]
+    if full_image:
+        out["full_image_640x480_stride2"] = {m: full_image[m]["seconds_per_image"] for m in full_image
+                                             if isinstance(full_image[m], dict)}
+        out["full_image_640x480_stride2"]["unit"] = "s/image incl. copy to host"
+    return out
 
 
 # softmax statistics written per point by gpn_view_attn for the semantic pass (0 once that side

@@ -2439,6 +2439,9 @@ k_ray1(gpn_ray_layer_t Lw, const float* x_in, int R, int S, float* x_out,
 #ifndef SEM_PREFETCH
 #define SEM_PREFETCH 0  // 1: taps of the next (sample, view) in flight (+40 VGPRs: measured slower than 4 waves per SIMD)
 #endif
+#if SEM_PREFETCH
+#error "SEM_PREFETCH=1 is stale: the prefetch pipeline predates `live = vis ? vis : (all_views & tab.hit)` and would blend the wrong taps"
+#endif
 typedef const __attribute__((address_space(4))) float* sem_cfp;
 __device__ __forceinline__ float rl_f(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
@@ -2968,7 +2971,19 @@ static int view_attn_launch(const gpn_view_layer_t* L, const float* q_in, const 
   GPN_REQUIRE_INT_RANGE(N, 1, V, "gpn_view_attn");
   const bool spl = precision == GPN_PREC_BF16X3;
   const bool fold = L->folded != nullptr;
-  const size_t lds = sizeof(float) * view_lds_floats(spl) + (VA_TPB / 64) * 2 * VA_SLOT_BYTES;
+  // the launch's dynamic LDS must hold the largest image of its phases: attention weights + DMA ring, the
+  // feed-forward weights, the q-MLP weights (the later phases re-stage from the base of the same allocation)
+  constexpr size_t LDS_CAP = 160 * 1024;
+  constexpr size_t va_lds_f = sizeof(float) * view_lds_floats(false) + (VA_TPB / 64) * 2 * VA_SLOT_BYTES;
+  constexpr size_t va_lds_s = sizeof(float) * view_lds_floats(true) + (VA_TPB / 64) * 2 * VA_SLOT_BYTES;
+  static_assert(va_lds_f <= LDS_CAP && va_lds_s <= LDS_CAP, "k_view_attn: attention image + ring exceed 160 KB");
+  static_assert(sizeof(float) * ff_lds_floats(false) <= LDS_CAP && sizeof(float) * ff_lds_floats(true) <= LDS_CAP,
+                "k_view_attn: feed-forward phase image exceeds 160 KB");
+  static_assert(sizeof(float) * qp_lds_floats(false) <= LDS_CAP && sizeof(float) * qp_lds_floats(true) <= LDS_CAP,
+                "k_view_attn: q-MLP phase image exceeds 160 KB");
+  size_t lds = spl ? va_lds_s : va_lds_f;
+  if (ff_out != nullptr) lds = std::max(lds, sizeof(float) * (size_t)ff_lds_floats(spl));
+  if (qp_out != nullptr) lds = std::max(lds, sizeof(float) * (size_t)qp_lds_floats(spl));
   const bool tiled = VA_TILED_DMA && fold && layout == 3;  // the fused path: scalar-base DMA addressing
   GPN_REQUIRE(ff_out == nullptr || (L->ff1.w && L->ff2.w && L->ff_norm_w && L->ff_norm_b),
               "gpn_view_attn: fused feed-forward without its weights");

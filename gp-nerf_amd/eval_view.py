@@ -15,9 +15,10 @@ from .semantic_branch import semantic_labels
 
 @torch.no_grad()
 def render_view(args, model, ray_sampler, projector, gt_img=None, render_stride=1, ret_alpha=False,
-                single_net=True, sharded=False, feats_out_3d=True):
+                single_net=True, sharded=False, feats_out_3d=True, shard_kw=None):
     """-> (ret, ray_batch): `ret` as render_single_image returns it plus, per level, 'sems'
-    [1,H,W,num_classes+1] (reference :201-206) and 'labels' [H,W] int64 (loss.py:296's argmax)."""
+    [1,H,W,num_classes+1] (reference :201-206) and 'labels' [H,W] int64 (loss.py:296's argmax).
+    shard_kw: extra keyword arguments for render_image_sharded (group, gather_weights; render_fn in tests)."""
     model.switch_to_eval()
     ray_batch = ray_sampler.get_all()
     src = ray_batch["src_rgbs"].squeeze(0).permute(0, 3, 1, 2)
@@ -29,7 +30,7 @@ def render_view(args, model, ray_sampler, projector, gt_img=None, render_stride=
               featmaps=ref_coarse_feats, deep_semantics=ref_deep_semantics, ret_alpha=ret_alpha,
               single_net=single_net)
     if sharded:
-        ret = render_image_sharded(ray_sampler, ray_batch, model, projector, **kw)
+        ret = render_image_sharded(ray_sampler, ray_batch, model, projector, **kw, **(shard_kw or {}))
     else:
         ret = render_single_image(ray_sampler=ray_sampler, ray_batch=ray_batch, model=model,
                                   projector=projector, feats_out_3d=feats_out_3d, **kw)
@@ -37,7 +38,10 @@ def render_view(args, model, ray_sampler, projector, gt_img=None, render_stride=
         if ret[lvl] is None:
             continue
         feats = ret[lvl]["feats_out"]
-        if args.render_stride == 1:  # reference :201-203: the head works on the half-resolution grid
+        # reference :201-203: the head works on the half-resolution grid.  (The reference tests
+        # args.render_stride there; every call site passes render_stride=args.render_stride, eval_gpnerf.py:128,
+        # so the two agree -- the parameter is what the image was rendered with.)
+        if render_stride == 1:
             feats = feats[::2, ::2, :]
         logits = model.sem_seg_head(feats.permute(2, 0, 1).unsqueeze(0).to(device), None, None)
         ret[lvl]["sems"] = logits.permute(0, 2, 3, 1)

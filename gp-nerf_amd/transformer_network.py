@@ -125,10 +125,12 @@ class GNT(nn.Module):
         self.in_feat_ch = in_feat_ch
         self._wcache = None
         self._ws = None
-        # 'bf16x3' (default): split-bf16 MFMA with fp32 accumulation, ~5e-6 of the tensor scale end to
-        # end against the reference's golden vectors (bar: 1e-4), 1.7x the rays/s of 'fp32'.
-        # 'fp32': exact fp32 MFMA (the arithmetic bench.py reports as its headline).  See include/gpnerf_hip.h.
-        self.precision = "bf16x3"
+        # 'fp32' (default): fp32 MFMA, fp32 accumulation -- the reference's arithmetic, what a drop-in caller
+        # gets without asking and what bench.py reports as its headline.
+        # 'bf16x3' (opt in: `net.precision = "bf16x3"`): split-bf16 MFMA with fp32 accumulation, ~5e-6 of the
+        # tensor scale end to end against the reference's golden vectors (same 1e-4 bar), 1.7x the rays/s.
+        # See include/gpnerf_hip.h (GPN_PREC_*).
+        self.precision = "fp32"
 
     # ------------------------------------------------------------------ weights -> C struct
     def _weights(self):
@@ -156,7 +158,8 @@ class GNT(nn.Module):
             L.pos0, L.pos2 = _lin(b.attn.pos_fc[0]), _lin(b.attn.pos_fc[2])
             L.attn0, L.attn2 = _lin(b.attn.attn_fc[0]), _lin(b.attn.attn_fc[2])
             L.out = _lin(b.attn.out_fc)
-            # folded weight products for the bf16x3 mode (include/gpnerf_hip.h: gpn_view_fold)
+            # folded weight products, used by gpn_view_attn in every arithmetic mode (include/gpnerf_hip.h:
+            # gpn_view_fold)
             fold = torch.empty(_lib.VIEW_FOLD_FLOATS, device=b.attn.q_fc.weight.device)
             _lib.check(_lib.lib().gpn_view_fold(C.byref(L), _lib.ptr(fold), _lib.stream()),
                        "gpn_view_fold")
@@ -176,16 +179,26 @@ class GNT(nn.Module):
         self._wcache = (key, W, folded)  # `folded` keeps the derived weight tensors alive
         return W
 
+    MAX_WORKSPACES = 4  # (device, stream) pairs kept; least recently used beyond that are dropped
+
     def _workspace(self, R, S, V, dev):
         """One workspace per (device, stream): two streams driving this module do not share scratch
-        memory (calls on ONE stream are ordered by the stream itself)."""
+        memory (calls on ONE stream are ordered by the stream itself).  At most MAX_WORKSPACES are kept
+        (least recently used first out): a caller that keeps creating short-lived streams does not pile up
+        multi-hundred-MB buffers.  A dropped workspace is freed through torch's caching allocator, which
+        keeps the block alive until the work already enqueued on its stream has run."""
         need = _lib.lib().gpn_gnt_workspace_bytes(R, S, V, self.trans_depth)
         if self._ws is None:
             self._ws = {}
-        key = (dev.index, int(torch.cuda.current_stream().cuda_stream))
-        ws = self._ws.get(key)
+        stream = torch.cuda.current_stream()
+        key = (dev.index, int(stream.cuda_stream))
+        ws = self._ws.pop(key, None)  # re-inserted below: dict order = recency
         if ws is None or ws.numel() < need:
-            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            ws.record_stream(stream)
+        self._ws[key] = ws
+        while len(self._ws) > self.MAX_WORKSPACES:
+            self._ws.pop(next(iter(self._ws)))
         return ws, need
 
     # ------------------------------------------------------------------ kernels

@@ -48,7 +48,9 @@ typedef void* gpn_stream_t;
 /* Arithmetic mode of the GNT linear layers (no counterpart in the reference, which is plain fp32);
  * an argument of gpn_rgbfeat / gpn_view_attn / gpn_ff / gpn_qpos / gpn_ray_attn and the `precision`
  * field of the weight struct gpn_gnt_forward takes.  (ABI 1 had a process-global switch instead.)
- *   GPN_PREC_FP32   v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation.
+ *   GPN_PREC_FP32   v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation (each linear layer is an
+ *                   fmaf chain).  The ray softmax is exp2 with log2(e) folded into the query scale; the view
+ *                   attention uses the folded weight products when gpn_view_layer_t.folded is set (below).
  *   GPN_PREC_BF16X3 every fp32 operand is split into two bf16 pieces (hi + mid) and a product is
  *                   w_mid*x_hi + w_hi*x_mid + w_hi*x_hi on v_mfma_f32_16x16x32_bf16 with fp32
  *                   accumulation: ~2^-16 relative error per product, 5.3x the MFMA rate.
@@ -177,8 +179,12 @@ typedef struct {                 /* Transformer2D + Attention2D, transformer_net
   gpn_linear_t pos0, pos2;       /* [C/8,4], [C,C/8] */
   gpn_linear_t attn0, attn2;     /* [C/8,C], [C,C/8] */
   gpn_linear_t out;              /* [C,C] */
-  /* Optional (may be NULL): products of the weights above, made by gpn_view_fold.  Used in
-   * GPN_PREC_BF16X3 mode only; the fp32 mode always follows the reference's operation order. */
+  /* Optional (may be NULL): products of the weights above, made by gpn_view_fold.  When set, gpn_view_attn
+   * uses them in EVERY arithmetic mode (k is never formed): in GPN_PREC_FP32 this re-associates the linear
+   * chains v_fc(k_fc(f)) and attn_fc[0](k - q + pos) -- products formed in fp64 and rounded to fp32 once,
+   * results within 2e-5 (relative to the tensor scale; measured ~1e-6) of the unfolded order and of
+   * the oracle (tests/test_gpu_parity.py::test_gnt_stages runs both and compares them with each other).  With folded == NULL the fp32 mode follows the reference's operation order
+   * literally (k_fc, then v_fc on its output; the sum k - q + pos formed before attn_fc[0]). */
   const float* folded;           /* [GPN_VIEW_FOLD_FLOATS] */
 } gpn_view_layer_t;
 

@@ -160,3 +160,16 @@ def g7_encoders():
     x = torch.from_numpy(synth.hash_uniform(4242, 9, (3, 3, 52, 72)))
     return dict(x=x, resunet=synth.hashed_state_dict(_resunet_shapes(), 777),
                 fpn=synth.hashed_state_dict(fpn_shapes(), 778))
+
+
+def g8_scannet_labels():
+    """BASELINE.json configs[2] at full size: ScanNet-shaped 240x320 view, 10 source views, hashed maps; the
+    19,200 rays of the half-resolution pixel grid the semantic head works on (feats_out[::2, ::2],
+    reference eval_gpnerf.py:201-203) and a hashed semantic head (20 classes + 1)."""
+    sc = synth.scannet_scene(V=10, seed=8086)
+    H, W = sc.H, sc.W
+    idx = (torch.arange(0, H, 2)[:, None] * W + torch.arange(0, W, 2)[None, :]).reshape(-1)
+    rb = sc.ray_batch()
+    rb["ray_o"], rb["ray_d"] = sc.rays_o[idx].contiguous(), sc.rays_d[idx].contiguous()
+    return dict(ray_batch=rb, featmaps=sc.featmaps, deep_semantics=sc.deep_semantics, H=H, W=W,
+                head=synth.hashed_state_dict(synth.sem_head_param_shapes(), 901))

@@ -91,7 +91,54 @@ def g7():
 
 
 @torch.no_grad()
+def g8():
+    """G8: BASELINE configs[2] at full size -- the reference's own render_rays (two passes, 48 + 16) on the
+    19,200 rays of the half-resolution grid of a 240x320 ScanNet-shaped view, then the semantic head and the
+    label image (eval_gpnerf.py:201-206, loss.py:296).  The head is the CPU restatement oracle/sem_head.py
+    (the reference's module needs detectron2 / fvcore: absent), so the labels are pinned to the reference
+    up to the head's input and to the restatement from there.  ~15 minutes on 8 cores."""
+    import time
+    import oracle
+    c = cases.g8_scannet_labels()
+    net = ref_gnt(cases.weights())
+    model = types.SimpleNamespace(net_coarse=net, net_fine=None)
+    proj = Projector("cpu")
+    rb = c["ray_batch"]
+    n = rb["ray_o"].shape[0]
+    keep = ("rgb", "depth", "feats_out")
+    outs = {lvl: {k: [] for k in keep} for lvl in ("outputs_coarse", "outputs_fine")}
+    t0 = time.time()
+    for i in range(0, n, 240):
+        chunk = dict(rb)
+        chunk["ray_o"], chunk["ray_d"] = rb["ray_o"][i:i + 240], rb["ray_d"][i:i + 240]
+        ret = render_rays(chunk, model, c["featmaps"], c["deep_semantics"], proj, N_samples=48, inv_uniform=True,
+                          N_importance=16, det=True, ret_alpha=True, single_net=True)
+        for lvl in outs:
+            for k in keep:
+                outs[lvl][k].append(ret[lvl][k].clone())
+        print("g8: %d / %d rays, %.0f s" % (i + 240, n, time.time() - t0), flush=True)
+    arrays = {}
+    h, w = c["H"] // 2, c["W"] // 2
+    for lvl, t in (("outputs_coarse", "coarse"), ("outputs_fine", "fine")):
+        o = {k: torch.cat(v, dim=0) for k, v in outs[lvl].items()}
+        feats = o["feats_out"].reshape(h, w, 512).permute(2, 0, 1).unsqueeze(0)
+        logits = oracle.sem_head.forward(c["head"], feats)  # [1,21,240,320]
+        top2 = logits[0].topk(2, dim=0).values
+        arrays.update({t + "_rgb": np_(o["rgb"]), t + "_depth": np_(o["depth"]),
+                       t + "_feats_sub": np_(o["feats_out"][::37]),
+                       t + "_feats_sum": np_(o["feats_out"].double().sum(-1)),
+                       t + "_labels": np_(logits[0].argmax(dim=0)).astype(np.uint8),
+                       t + "_margin": np_(top2[0] - top2[1]),
+                       t + "_logits_sub": np_(logits[0, :, ::4, ::4]),
+                       t + "_logits_absmax": np.float64(logits.abs().max().item())})
+    save("g8_scannet_labels", sha=cases.sha(dict(rb=rb, f=c["featmaps"], d=c["deep_semantics"], h=c["head"])),
+         **arrays)
+
+
+@torch.no_grad()
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "g8":
+        return g8()
     if len(sys.argv) > 1 and sys.argv[1] == "g6":
         return g6()
     if len(sys.argv) > 1 and sys.argv[1] == "g7":
@@ -173,6 +220,7 @@ def main():
     save("g5_render_image", sha=cases.sha(c), **arrays)
     g6()
     g7()
+    g8()
 
 
 if __name__ == "__main__":

@@ -284,3 +284,70 @@ def test_sharded_render_world4_rank_without_rows(kw):
     if kw.get("gather_weights"):
         assert one["outputs_fine"]["weights"].shape == (H, W, N_S + N_I)
         assert one["outputs_coarse"]["weights"].shape == (H, W, N_S)
+
+
+# ------------------------------------------------------------------ render_view(sharded=True) on gloo, world 4
+class _FakeViewModel:
+    """Duck-typed GPNeRFModel for the host logic of render_view: CPU stand-ins for the encoders and the head
+    (the head, like the real one, needs the whole feature image: its mean enters every logit)."""
+
+    def switch_to_eval(self):
+        pass
+
+    def feature_net(self, src):
+        return torch.zeros(src.shape[0], 32, 2, 2), None, [torch.zeros(1)]
+
+    def feature_fpn(self, feats):
+        return torch.zeros(1, 512, 2, 2)
+
+    def sem_seg_head(self, feats, a, b):
+        x = feats[0, :21] - feats.mean()
+        return torch.nn.functional.interpolate(x[None], scale_factor=2, mode="nearest")
+
+
+def _view_worker(rank, world, port, H, W, q):
+    import torch.distributed as dist
+    from gp_nerf_amd import eval_view
+    eval_view.semantic_labels = lambda logits: logits[0].argmax(dim=0)  # the HIP epilogue refuses CPU tensors
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    args = types.SimpleNamespace(chunk_size=50, N_samples=N_S, inv_uniform=True, N_importance=N_I, white_bkgd=False,
+                                 render_stride=1)
+    sampler = types.SimpleNamespace(H=H, W=W, get_all=lambda: {"ray_o": torch.zeros(H * W, 3),
+                                                               "src_rgbs": torch.zeros(1, 2, 4, 4, 3)})
+    ret, _ = eval_view.render_view(args, _FakeViewModel(), sampler, None, render_stride=1, ret_alpha=True,
+                                   sharded=True, shard_kw=dict(render_fn=_fake_render))
+    q.put((rank, {l: {k: v.numpy().copy() for k, v in ret[l].items()} for l in ret}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_render_view_sharded_world4_equals_one_rank():
+    """render_view(sharded=True) -- encoders, sharded render, head, label image -- in a 4-rank gloo job gives,
+    on EVERY rank, the image a 1-rank call gives: rgb / depth / feats_out / sems / labels bit for bit
+    (H' = 6 over 4 ranks: the last rank owns no rows).  Reference eval_gpnerf.py:172-206 on
+    render_image.py:39-62's loop, sharded."""
+    H, W = 6, 8
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_view_worker, args=(r, 4, port, H, W, q)) for r in range(4)]
+    procs.append(ctx.Process(target=_view_worker, args=(9, 1, 0, H, W, q)))  # the 1-rank image
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(5))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    one = res[9]
+    for r in range(4):
+        for lvl in ("outputs_coarse", "outputs_fine"):
+            assert set(res[r][lvl]) == {"rgb", "depth", "feats_out", "sems", "labels"}
+            for k in res[r][lvl]:
+                assert np.array_equal(res[r][lvl][k], one[lvl][k]), (r, lvl, k)
+    assert one["outputs_fine"]["labels"].shape == (H, W) and one["outputs_fine"]["sems"].shape == (1, H, W, 21)

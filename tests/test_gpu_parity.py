@@ -386,6 +386,9 @@ def test_gnt_stages(dev, net, prec, S):
                                        _lib.ptr(mk), None, N, V, _lib.ptr(qo_p), None, 64, None, 64, pc, st),
                        "view-unfolded")
             errs["view_attn_unfolded"] = rel(qo_p, rec["q_view_attn"][l].reshape(N, 64))
+            # folded against unfolded directly (include/gpnerf_hip.h, gpn_view_layer_t.folded: the fp32 mode
+            # re-associates the linear chains when the folded products are given)
+            errs["view_attn_folded_vs_unfolded"] = rel(qo, qo_p)
         if l == 0:  # rows gpn_rgbfeat leaves unstored (NaN here) must not reach the result
             feat_nan = feat_ref.clone()
             feat_nan[~stored] = float("nan")
@@ -931,7 +934,36 @@ def test_render_rays_stress_shape(dev, net, prec):
 
 
 # ------------------------------------------------------------------------------ ray generation (8(f) rank 1)
-@pytest.mark.parametrize("rig,mode", [("sparse", "bf16x3"), ("dense", "fp32"), ("stress", "bf16x3")])
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+def test_north_star_chunk_vs_oracle(dev, mode):
+    """The north-star size against the oracle inside the test suite: the first 192 rays of bench.py's chunk on
+    the full 640x480 x 10-view Replica-shaped scene, two passes (48 + 16 samples), HIP path vs
+    oracle.render.render_rays (reference render_ray.py:229-298), every output of both levels within 1e-4 of the
+    tensor scale.  Rays whose importance samples or fine-level visibility differ between the two platforms
+    (inverse-CDF knife edges) are counted and left out of the fine level; there must be
+    few of them.  Chunk invariance (test_full_size_properties) carries the result to the 4096-ray chunk."""
+    import bench
+    from gp_nerf_amd.render_ray import render_rays
+    NR = 192
+    scene, gnt, projector = bench.build(dev)
+    gnt.precision = mode
+    rb = bench.ray_chunk(scene, 0, 1, dev)
+    sub = dict(rb)
+    sub["ray_o"], sub["ray_d"] = rb["ray_o"][:NR].contiguous(), rb["ray_d"][:NR].contiguous()
+    got = render_rays(sub, types.SimpleNamespace(net_coarse=gnt, net_fine=None), scene.featmaps, scene.deep,
+                      projector, N_samples=48, inv_uniform=True, N_importance=16, det=True, ret_alpha=True,
+                      single_net=True)
+    want, info = bench.cpu_baseline(scene, sub, NR)
+    err, resampled = bench.compare_with_cpu(scene, sub, projector, got, want, NR, dev)
+    print("north-star chunk [%s]: max rel err %.2e vs the CPU oracle on %d rays (%d resampled fine rays left out); "
+          "oracle %s" % (mode, err, NR, resampled, info["sample"]))
+    assert resampled <= NR // 20, resampled
+    assert err < TOL, err
+    # the semantic side outputs too (compare_with_cpu covers rgb / depth / weights / feats_out)
+    assert rel(got["outputs_coarse"]["feats_out_3d"], want["outputs_coarse"]["feats_out_3d"]) < TOL
+
+
+@pytest.mark.parametrize("rig,mode", [("sparse", "fp32"), ("sparse", "bf16x3"), ("dense", "fp32"), ("stress", "bf16x3")])
 def test_full_size_properties(dev, rig, mode):
     """BASELINE.json configs[1] at full size (4096 rays, 48 + 16 samples, 10 views, 640x480 maps: too big
     for the CPU oracle in a test) through size-independent properties of the path:
@@ -941,7 +973,8 @@ def test_full_size_properties(dev, rig, mode):
     * linearity in the deep-semantic maps: doubling the maps doubles feats_out_3d
       exactly and leaves rgb / weights / depth untouched bit for bit.
     Both visibility regimes of the bench: the sparse rig (~41 % of the pairs visible,
-    most tiles skip views) and the dense rig (~96 %, nearly every view computed), one arithmetic mode each.
+    most tiles skip views; both arithmetic modes -- sparse / fp32 is the bench headline) and the dense rig
+    (~96 %, nearly every view computed).
     "stress" = BASELINE.json configs[4] at full size on one GPU: 16 views of 1296x968 images, 96 + 32
     samples (a 96- and a 128-sample pass)."""
     import bench
@@ -1230,6 +1263,67 @@ def test_scannet_eval_view_full_size(dev):
     print("scannet view: fp32 vs bf16x3 logits differ by %.2e (scale %.2f); %.4f of the pixels have a top-2 margin above 4x that"
           % (diff, float(lx.abs().max()), float(clear.float().mean())))
     assert float(clear.float().mean()) > 0.9
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+def test_scannet_labels_vs_reference_chain(dev, net, mode, golden):
+    """BASELINE.json configs[2] at full size against THE REFERENCE's renderer: golden g8 holds, for the 19,200
+    rays of the half-resolution grid of a 240x320 ScanNet-shaped view (10 views, 48 + 16 samples), the
+    reference's rgb / depth / feats_out and the label image + top-2 logit margins its features give through
+    the semantic head (head = CPU restatement, detectron2 absent: pinned to the reference up to the head's
+    input).  The HIP chain (render_rays -> device head -> gpn_argmax_labels) must reproduce rgb / depth /
+    feats_out within 1e-4 and the labels wherever the margin exceeds the logit error; the label AGREEMENT RATE
+    over all 76,800 pixels is reported and bounded (north_star: argmax labels)."""
+    from gp_nerf_amd.projection import Projector
+    from gp_nerf_amd.render_ray import render_rays
+    from gp_nerf_amd.semantic_branch import NeRFSemSegFPNHead, semantic_labels
+    g = golden("g8_scannet_labels")
+    c = cases.g8_scannet_labels()
+    assert np.array_equal(cases.sha(dict(rb=c["ray_batch"], f=c["featmaps"], d=c["deep_semantics"], h=c["head"])),
+                          g["sha"])
+    net.precision = mode
+    rb = to(dev, c["ray_batch"])
+    fm, deep = c["featmaps"].to(dev), c["deep_semantics"].to(dev)
+    P = Projector(dev)
+    n = rb["ray_o"].shape[0]
+    outs = {lvl: {k: [] for k in ("rgb", "depth", "feats_out")} for lvl in ("outputs_coarse", "outputs_fine")}
+    for i in range(0, n, 4096):
+        chunk = dict(rb)
+        chunk["ray_o"], chunk["ray_d"] = rb["ray_o"][i:i + 4096].contiguous(), rb["ray_d"][i:i + 4096].contiguous()
+        ret = render_rays(chunk, _model(net), fm, deep, P, N_samples=48, inv_uniform=True, N_importance=16,
+                          det=True, ret_alpha=True, single_net=True)
+        for lvl in outs:
+            for k in outs[lvl]:
+                outs[lvl][k].append(ret[lvl][k])
+    head = NeRFSemSegFPNHead(types.SimpleNamespace(), num_classes=20)
+    head.load_state_dict(c["head"], strict=True)
+    head = head.to(dev).eval()
+    h, w = c["H"] // 2, c["W"] // 2
+    report = {}
+    for lvl, t in (("outputs_coarse", "coarse"), ("outputs_fine", "fine")):
+        o = {k: torch.cat(v, dim=0) for k, v in outs[lvl].items()}
+        errs = {"rgb": rel(o["rgb"], g[t + "_rgb"]), "depth": rel(o["depth"], g[t + "_depth"]),
+                "feats_sub": rel(o["feats_out"][::37], g[t + "_feats_sub"]),
+                "feats_sum": rel(o["feats_out"].double().sum(-1), g[t + "_feats_sum"])}
+        with torch.no_grad():
+            logits = head(o["feats_out"].reshape(h, w, 512).permute(2, 0, 1).unsqueeze(0))
+        labels = semantic_labels(logits).cpu().numpy()
+        lerr_abs = float(np.abs(logits[0, :, ::4, ::4].cpu().numpy() - g[t + "_logits_sub"]).max())
+        errs["logits_sub"] = lerr_abs / max(1.0, float(g[t + "_logits_absmax"]))
+        agree = labels == g[t + "_labels"]
+        clear = g[t + "_margin"] > 4 * lerr_abs
+        report[t] = dict(errs=errs, agree=int(agree.sum()), pixels=int(agree.size), clear=float(clear.mean()),
+                         wrong_where_clear=int((~agree & clear).sum()))
+    print("scannet labels vs the reference chain [%s]: %s" % (mode, report))
+    net.precision = "fp32"
+    # coarse level: continuous in the arithmetic -> the full bar; fine level: rays whose importance samples
+    # cross a knife edge differ by O(1) in feats_out on any two platforms (DESIGN.md section 5), so its
+    # tensors are bounded loosely and its labels only counted
+    assert max(report["coarse"]["errs"].values()) < TOL, report["coarse"]
+    assert report["coarse"]["wrong_where_clear"] == 0, report["coarse"]
+    assert report["coarse"]["agree"] >= 0.999 * report["coarse"]["pixels"], report["coarse"]
+    assert report["fine"]["errs"]["rgb"] < 5e-2 and report["fine"]["agree"] >= 0.99 * report["fine"]["pixels"], \
+        report["fine"]
 
 
 def test_sem_head_direct_vs_oracle(dev):

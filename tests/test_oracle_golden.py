@@ -160,3 +160,31 @@ def test_g7_resunet(golden):
     # FPN: parity unpinned (mmcv / mmdet absent); shape + determinism only
     out = oracle.encoders.fpn_forward(c["fpn"], feats)
     assert tuple(out.shape) == (3, 512, 26, 36) and torch.isfinite(out).all()
+
+
+def test_oracle_on_the_full_size_scannet_view(golden):
+    """Golden g8 (the reference's renderer on the 19,200 half-grid rays of a 240x320 ScanNet-shaped view,
+    BASELINE.json configs[2]): the oracle on every 800th of those rays, two passes, against the reference's
+    rgb / depth / feats_out; and the label image the golden holds is the argmax the restated head gives
+    on the golden's own logits subsample."""
+    g = golden("g8_scannet_labels")
+    c = cases.g8_scannet_labels()
+    assert np.array_equal(cases.sha(dict(rb=c["ray_batch"], f=c["featmaps"], d=c["deep_semantics"], h=c["head"])),
+                          g["sha"])
+    sel = torch.arange(0, 19200, 800)
+    rb = dict(c["ray_batch"])
+    rb["ray_o"], rb["ray_d"] = rb["ray_o"][sel].contiguous(), rb["ray_d"][sel].contiguous()
+    out = oracle.render.render_rays(rb, cases.weights(), c["featmaps"], c["deep_semantics"], N_samples=48,
+                                    inv_uniform=True, N_importance=16, det=True, ret_alpha=True)
+    for lvl, t in (("outputs_coarse", "coarse"), ("outputs_fine", "fine")):
+        for k in ("rgb", "depth"):
+            want = torch.from_numpy(g[t + "_" + k])[sel]
+            err = float((out[lvl][k] - want).abs().max() / max(1.0, float(want.abs().max())))
+            assert err < (2e-5 if t == "coarse" else 1e-3), (lvl, k, err)
+        want = torch.from_numpy(g[t + "_feats_sum"])[sel]
+        err = float((out[lvl]["feats_out"].double().sum(-1) - want).abs().max() / max(1.0, float(want.abs().max())))
+        assert err < (2e-5 if t == "coarse" else 1e-2), (lvl, err)
+        lab = g[t + "_labels"]
+        assert lab.shape == (240, 320) and lab.max() <= 20
+        assert np.array_equal(g[t + "_logits_sub"].argmax(0), lab[::4, ::4])
+        assert (g[t + "_margin"] >= 0).all()

@@ -66,6 +66,29 @@ def test_static_forward_matches_workspace_forward(prec):
             assert bool(torch.isfinite(a).all()), name
             assert torch.equal(a.view(torch.int32), b.view(torch.int32)), \
                 "%s differs between the static and the caller workspace (S=%d R=%d, %s)" % (name, S, R, prec)
+    # the entry point's defining property: it allocates nothing.  With every tensor made beforehand and one
+    # warm call behind us, neither the device's free memory (hipMemGetInfo: sees a hipMalloc by anyone in this
+    # process) nor torch's allocator statistics move across further calls.
+    c = cases.g2_gnt(48, R=24)
+    R, S, V = c["rgb_feat"].shape[:3]
+    f = lambda t: t.to(dev).float().contiguous()
+    rgbf, deep, rd = f(c["rgb_feat"]), f(c["deep_sem"]), f(c["ray_diff"])
+    mk, pts, ray_d = f(c["mask"]).reshape(R, S, V), f(c["pts"]), f(c["ray_d"])
+    out, semf, sem3d = torch.empty(R, 3 + S, device=dev), torch.empty(R, 512, device=dev), torch.empty(R, S, 512, device=dev)
+    sem = _lib.SemArgs()
+    sem.deep_dense, sem.sem3d = _lib.ptr(deep), _lib.ptr(sem3d)
+    st = _lib.stream()
+    call = lambda: L.gpn_gnt_forward_static(C.byref(W), _lib.ptr(rgbf), 35, _lib.ptr(rd), _lib.ptr(mk), _lib.ptr(pts),
+                                            _lib.ptr(ray_d), None, R, S, V, C.byref(sem), _lib.ptr(out), None,
+                                            _lib.ptr(semf), st)
+    assert call() == 0
+    torch.cuda.synchronize()
+    free0, alloc0, resv0 = torch.cuda.mem_get_info(dev)[0], torch.cuda.memory_allocated(dev), torch.cuda.memory_reserved(dev)
+    for _ in range(3):
+        assert call() == 0
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(dev)[0] == free0, "gpn_gnt_forward_static changed the device's free memory"
+    assert torch.cuda.memory_allocated(dev) == alloc0 and torch.cuda.memory_reserved(dev) == resv0
     # a chunk beyond the static workspace is refused with a message, before any launch
     big_R = 4096
     assert L.gpn_gnt_workspace_bytes(big_R, 64, 10, 8) > _lib.STATIC_WS_BYTES

@@ -116,6 +116,8 @@ QPOS_FLOPS_PER_POINT = 2 * (192 * 64 + 64 * 64)  # q MLP on [q | emb_pt | emb_ra
 
 
 def mfma_peak(precision):
+    if precision == "bf16":
+        return BF16_MATRIX_PEAK_TFLOPS, "dense bf16 MFMA peak (one bf16 MFMA per product)"
     if precision == "bf16x3":
         return BF16_MATRIX_PEAK_TFLOPS / 3.0, "dense bf16 MFMA peak / 3 (three bf16 MFMAs per fp32 product)"
     return FP32_MATRIX_PEAK_TFLOPS, "fp32 MFMA peak"
@@ -243,7 +245,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-rays", type=int, default=1536, help="rays of the CPU baseline sample (0: skip)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-stage time table to stderr")
-    ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16x3"),
+    ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16x3", "bf16"),
                     help="arithmetic of the headline numbers (the other mode is reported under its own key)")
     ap.add_argument("--only-timed", action="store_true",
                     help="skip the other arithmetic mode, the extra legs, the full-image run and the CPU baseline "
@@ -372,7 +374,7 @@ def main():
         s_mean = sum(samples) / float(len(samples))
         live = vstat["computed_pair_fraction"]
         peak, peak_note = mfma_peak(precision)
-        mult = 3 if precision == "bf16x3" else 1  # MFMA flops issued per algorithmic flop
+        mult = 3 if precision == "bf16x3" else 1  # MFMA flops issued per algorithmic flop (fp32, bf16: one)
         blocks = {}
         # ---- the view launch: attention (HBM-bound in bf16x3) + feed-forward + q MLP on every second layer
         n_va = max(1, tm.launches["view_attn"])
@@ -383,7 +385,7 @@ def main():
         # (half of the launches): q in + out + the point's encoding 768
         alg_bytes = (VIEWS * live * (256 + 16) + VIEWS * vstat["visible_pair_fraction"] * 32 +
                      256 + 256 + VIEW_STATS_BYTES + 8 + 512 + 0.5 * 768) * pts_per_launch
-        traffic, tsrc = pmc_traffic("k_view_attn" if precision == "bf16x3" else "k_view_attn_fp32")
+        traffic, tsrc = pmc_traffic("k_view_attn" if precision != "fp32" else "k_view_attn_fp32")
         va_alg = (VIEWS * live * VIEW_ALG_FLOPS_PER_PAIR + VIEW_ALG_FLOPS_PER_POINT + FF_FLOPS_PER_POINT +
                   0.5 * QPOS_FLOPS_PER_POINT) * pts_per_launch
         va_ref = (view_attn_flops_per_point(VIEWS) + FF_FLOPS_PER_POINT + 0.5 * 32512) * pts_per_launch
@@ -406,7 +408,7 @@ def main():
         ra_ms = max(tm.ms["ray_attn"] / n_ra, 1e-9)
         ra_alg = (4 * 8192 + 256 * s_mean + FF_FLOPS_PER_POINT) * pts_per_launch
         ra_bytes = (256 + 256 + 16 + 512) * pts_per_launch  # x in / out, mean attention row 16; feed-forward 512
-        sfx = "" if precision == "bf16x3" else "_fp32"
+        sfx = "" if precision != "fp32" else "_fp32"
         rt = [pmc_traffic(k + sfx)[0] for k in ("k_ray1_s48", "k_ray_attn_s64")]  # the two passes of a step
         rtraffic = (sum(rt) / len(rt)) if all(t is not None for t in rt) and len(samples) == 2 else None
         blocks["ray_attn"] = {
@@ -420,8 +422,8 @@ def main():
         # dominant = larger share of the step; priced against the roofline that bounds its largest phase in
         # this mode (bf16x3: the attention phase of k_view_attn is HBM-bound; fp32: MFMA)
         if dom_stage == "view_attn":
-            main_ = dict(blocks["view_attn"]["hbm" if precision == "bf16x3" else "mfma"])
-            main_["mfma" if precision == "bf16x3" else "hbm"] = blocks["view_attn"]["mfma" if precision == "bf16x3" else "hbm"]
+            main_ = dict(blocks["view_attn"]["hbm" if precision != "fp32" else "mfma"])
+            main_["mfma" if precision != "fp32" else "hbm"] = blocks["view_attn"]["mfma" if precision != "fp32" else "hbm"]
         else:
             main_ = dict(blocks["ray_attn"]["mfma"])
         main_["step_share"] = blocks[dom_stage]["step_share"]
@@ -467,13 +469,13 @@ def main():
     if a.breakdown and rank == 0:
         print("per-stage ms (one step, %s):" % a.precision, json.dumps(stages), file=sys.stderr)
 
-    other = None
-    omode = "bf16x3" if a.precision == "fp32" else "fp32"
-    if not a.only_timed:  # the other arithmetic mode on the same workload (every rank takes part)
-        ret_o, other = measure(two_pass, omode, a.steps, 2, samples2, scene, rb, N_SAMPLES, N_IMPORTANCE)
+    # the other arithmetic modes on the same workload (every rank takes part)
+    omodes = [m for m in ("fp32", "bf16x3", "bf16") if m != a.precision]
+    others, rets_o = {}, {}
+    if not a.only_timed:
+        for om in omodes:
+            rets_o[om], others[om] = measure(two_pass, om, a.steps, 2, samples2, scene, rb, N_SAMPLES, N_IMPORTANCE)
         net.precision = a.precision
-    else:
-        ret_o = None
 
     legs = None
     if rank == 0 and world == 1 and not a.only_timed:
@@ -497,7 +499,7 @@ def main():
         full_image = {"workload": "render_single_image, replica 640x480 render_stride 2 (%d rays), chunk %d, "
                                   "rgb/depth/weights/feats_out of both levels copied to the host; "
                                   "feats_out_3d not materialised" % (idx.numel(), CHUNK)}
-        for mode in (a.precision, omode):
+        for mode in [a.precision] + omodes:
             net.precision = mode
             best = None
             for _ in range(3):
@@ -516,7 +518,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and a.cpu_rays > 0:
         want, cpu = cpu_baseline(scene, rb, a.cpu_rays)
-        for mode, r in ((a.precision, ret), (omode, ret_o)):
+        for mode, r in [(a.precision, ret)] + list(rets_o.items()):
             if r is not None:
                 err, resampled = compare_with_cpu(scene, rb, projector, r, want, a.cpu_rays, dev)
                 cpu["max_rel_err_gpu_vs_cpu_" + mode] = err
@@ -535,8 +537,8 @@ def main():
         rank_ms = None
 
     if rank == 0:
-        detail = {"headline": dict(head, stage_ms_one_step=stages), omode: other, "legs": legs,
-                  "full_image": full_image, "cpu_baseline": cpu}
+        detail = dict({"headline": dict(head, stage_ms_one_step=stages), "legs": legs,
+                       "full_image": full_image, "cpu_baseline": cpu}, **others)
         legs_file = write_detail(detail)
         line = {
             "metric": "rays_per_sec", "value": head["value"], "unit": "rays/s", "n_gpus": world,
@@ -550,7 +552,7 @@ def main():
             "roofline": compact_roofline(head["roofline"]),
             "path_vs_reference_flops": compact_path(head["path_mfma"], head["roofline"]),
             "cpu_baseline": compact_cpu(cpu, a.precision),
-            "other_modes": {omode: compact_mode(other)} if other else None,
+            "other_modes": {m: compact_mode(o) for m, o in others.items()} or None,
             "legs": compact_legs(legs, full_image),
             "stage_ms_one_step": {k: round(v, 3) for k, v in stages.items()},
             "detail_file": legs_file,
@@ -771,7 +773,7 @@ def run_leg(name, a, dev, scene, rb, net, model, projector, make_step, measure, 
                            "samples (%d- and %d-sample passes), chunk %d rays"
                            % (V, W, H, ns, ni, ns, ns + ni, CHUNK)}
         f_ref = f_ref_per_ray(V, [ns, ns + ni]) * CHUNK
-        for mode in ("fp32", "bf16x3"):
+        for mode in ("fp32", "bf16x3", "bf16"):  # "bf16": configs[4] names "bf16 attention"
             net.precision = mode
             for _ in range(2):
                 r = step()

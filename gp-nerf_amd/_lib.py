@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GPN_LIB: developer override used to A/B kernel build variants; the default is the in-tree library
 LIB_PATH = os.environ.get("GPN_LIB") or os.path.join(_HERE, "csrc", "libgpnerf_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_DEPTH = 8
 MAX_VIEWS = 32
 MAX_SAMPLES = 128
@@ -208,11 +208,12 @@ class stage_timing:
         return False
 
 
-PRECISIONS = {"fp32": 0, "bf16x3": 1}  # GPN_PREC_* of include/gpnerf_hip.h
+PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2}  # GPN_PREC_* of include/gpnerf_hip.h
 
 
 def precision_code(mode):
-    """'fp32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 MFMA, fp32 accumulate) -> GPN_PREC_*.  The mode
+    """'fp32' (exact fp32 MFMA), 'bf16x3' (split-bf16 MFMA, fp32 accumulate) or 'bf16' (plain bf16 operands,
+    one MFMA per product, fp32 accumulate: looser tolerance) -> GPN_PREC_*.  The mode
     is an argument of every call (ABI 2): there is no process-wide switch."""
     try:
         return PRECISIONS[mode]

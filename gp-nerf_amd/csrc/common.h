@@ -44,4 +44,5 @@ class GpnStageTimer {
               "%s: R*S*V = %lld does not fit a 32-bit int (render in smaller chunks)", (name),   \
               (long long)(R) * (S) * ((V) > 0 ? (V) : 1))
 #define GPN_REQUIRE_PREC(p, name)                                                                \
-  GPN_REQUIRE((p) == GPN_PREC_FP32 || (p) == GPN_PREC_BF16X3, "%s: unknown precision %d", (name), (int)(p))
+  GPN_REQUIRE((p) == GPN_PREC_FP32 || (p) == GPN_PREC_BF16X3 || (p) == GPN_PREC_BF16, "%s: unknown precision %d", \
+              (name), (int)(p))

@@ -229,7 +229,7 @@ __global__ void k_posenc(const float* __restrict__ pts, const float* __restrict_
 // ------------------------------------------------------------------------------------ rgbfeat
 // LDS: W0 [64][52] (in_ch zero-padded to 48), W2 [64][68], b0 [64], b2 [64]
 #define RF_LD0 52
-template <bool SPL>
+template <int SPL>
 __global__ void __launch_bounds__(RF_TPB)
 k_rgbfeat(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ rgb_feat, long long N, int V,
           int in_ch, int in_ld, const float* __restrict__ mask, float* __restrict__ feat,
@@ -319,11 +319,11 @@ k_rgbfeat(gpn_linear_t fc0, gpn_linear_t fc2, const float* __restrict__ rgb_feat
       lin<SPL, 3, 4>(W0, RF_LD0, x, h, lane);
 #pragma unroll
       for (int M = 0; M < 4; ++M) {
-        h[M] = f4_relu_t<SPL>(h[M]);
+        h[M] = f4_relu_t<(SPL != 0)>(h[M]);
         y[M] = ld4(b2 + 16 * M + 4 * g);
       }
       lin<SPL, 4, 4>(W2, LDW, h, y, lane);
-      if constexpr (SPL) {
+      if constexpr (SPL != 0) {
         // split encoding of a feature row (gnt_mfma.h: feat_row_*): the operand split is done once
         // here instead of once per transformer layer in k_view_attn
         if ((wr >> (v & 31)) & 1u) store_feat_split(feat + ((size_t)nc * V + v) * C64, y, g);
@@ -396,7 +396,7 @@ k_proj_mask(gpn_project_args_t a) {
 // of a (tile, view) pair are one contiguous 4 KB block, read back by k_view_attn as whole sequential
 // lines -- and, with rdp != nullptr, its ray_diff to the tile-major image of k_rd_pack.  Slots past N
 // repeat the last slot's point (rows written, q0 not).
-template <bool SPL>
+template <int SPL>
 __global__ void __launch_bounds__(PR_TPB)
 k_proj_rgbfeat(gpn_project_args_t a, gpn_linear_t fc0, gpn_linear_t fc2, float* __restrict__ feat,
                float* __restrict__ q0, const int* __restrict__ perm, float* __restrict__ rdp, int tiled) {
@@ -414,7 +414,7 @@ k_proj_rgbfeat(gpn_project_args_t a, gpn_linear_t fc0, gpn_linear_t fc2, float* 
   {
     // fc0's image with the columns in gather order: [feature 0..31 | r g b | 0 ...]  (reference order: rgb first)
     const int in_ch = 3 + a.feat_c;
-    if constexpr (SPL) {
+    if constexpr (SPL != 0) {
       bf8* dst = reinterpret_cast<bf8*>(W0);
       for (int idx = tid; idx < 64 * 8; idx += PR_TPB) {  // 64 rows x (2 K pairs x 4 g)
         const int row = idx >> 3, u = idx & 7, P = u >> 2, g = u & 3;
@@ -462,14 +462,14 @@ k_proj_rgbfeat(gpn_project_args_t a, gpn_linear_t fc0, gpn_linear_t fc2, float* 
     lin<SPL, 3, 4>(W0, RF_LD0, x, h, lane);
 #pragma unroll
     for (int M = 0; M < 4; ++M) {
-      h[M] = f4_relu_t<SPL>(h[M]);
+      h[M] = f4_relu_t<(SPL != 0)>(h[M]);
       y[M] = ld4(b2 + 16 * M + 4 * g);
     }
     lin<SPL, 4, 4>(W2, LDW, h, y, lane);
   };
   auto store_row = [&](long long n, long long tile_, int v, const f4* y) {
     float* row = feat + (tiled ? (((size_t)tile_ * V + v) * 16 + (lane & 15)) : ((size_t)n * V + v)) * C64;
-    if constexpr (SPL) {
+    if constexpr (SPL != 0) {
       store_feat_split(row, y, g);
     } else {
 #pragma unroll
@@ -702,7 +702,7 @@ struct ViewLds {
   float *Wq, *Wk, *Wv, *Wo, *P2, *A0, *A2, *P0, *bP0, *bP2, *bA0, *bA2, *bO, *gam, *bet;
   float *AF, *c0;  // folded mode: (A0 Wk | A0 P2) image and the constant A0 b_pos2 + b_attn0
 };
-template <bool SPL>
+template <int SPL>
 __device__ __forceinline__ ViewLds view_lds(float* s) {
   static_assert(16 * VA_LDAF <= 64 * LDW, "the fp32 folded image must fit the unused Wk slot");
   ViewLds L;
@@ -804,7 +804,7 @@ constexpr int ff_lds_floats(bool spl) {
 struct FfLds {
   float *W1, *W2, *b1, *b2, *gam, *bet;
 };
-template <bool SPL>
+template <int SPL>
 __device__ __forceinline__ FfLds ff_lds() {
   FfLds L;
   L.W1 = smem;
@@ -817,7 +817,7 @@ __device__ __forceinline__ FfLds ff_lds() {
 }
 // two-phase staging (gnt_mfma.h): every global load first (load), then the LDS images (store); as a later
 // phase of an attention kernel the loads are issued BEFORE the barrier that frees LDS
-template <bool SPL, int TPB>
+template <int SPL, int TPB>
 struct FfStager {
   WStage<SPL, 256, 4, TPB> s1;
   WStage<SPL, 64, 16, TPB> s2;
@@ -834,7 +834,7 @@ struct FfStager {
     v1.store(L.b1, tid), v2.store(L.b2, tid), vg.store(L.gam, tid), vb.store(L.bet, tid);
   }
 };
-template <bool SPL, int TPB>
+template <int SPL, int TPB>
 __device__ __forceinline__ void ff_stage(const FfLds& L, const float* __restrict__ norm_w,
                                          const float* __restrict__ norm_b, const gpn_linear_t& fc1,
                                          const gpn_linear_t& fc2, int tid) {
@@ -861,12 +861,12 @@ __device__ __forceinline__ void ff_prefetch(f4 (&xpre)[FF_NTL][4], const float* 
 // REV: walk the tiles from the last to the first -- as a later phase of an attention kernel the rows a wave
 // wrote LAST are the ones still in L2 (a workgroup writes 200-260 KB per phase, its share of the L2 is 128 KB:
 // re-reading in writing order would miss on every row)
-template <bool SPL, bool REV, class PT>
+template <int SPL, bool REV, class PT>
 __device__ __forceinline__ void ff_run(const FfLds& L, [[maybe_unused]] f4 (&xpre)[FF_NTL][4],
                                        const float* x_in, float* x_out, long long nu, int lane,
                                        PT&& pt) {
   const int j = lane & 15, g = lane >> 4;
-  if constexpr (SPL) {
+  if constexpr (SPL != 0) {
     // FF_NTL point tiles per wave iteration; the hidden layer is produced and consumed in four 64-wide
     // chunks, so the 256 hidden values of a point never exist at once
     constexpr int NTL = FF_NTL;
@@ -903,14 +903,14 @@ __device__ __forceinline__ void ff_run(const FfLds& L, [[maybe_unused]] f4 (&xpr
         for (int t = 0; t < NTL; ++t)
 #pragma unroll
           for (int M = 0; M < 4; ++M) h[t][M] = ld4(L.b1 + 64 * c + 16 * M + 4 * g);
-        lin_S2<2, 2, 4, NTL>(w1p + (4 * c * 2) * 128, xs, h);  // rows 64c.., all 64 inputs
+        lin_S2<2, 2, 4, NTL, bf_terms(SPL)>(w1p + (4 * c * 2) * 128, xs, h);  // rows 64c.., all 64 inputs
         XS hs[NTL][2];
 #pragma unroll
         for (int t = 0; t < NTL; ++t) {
           hs[t][0] = split8(f4_relu_t<true>(h[t][0]), f4_relu_t<true>(h[t][1]));
           hs[t][1] = split8(f4_relu_t<true>(h[t][2]), f4_relu_t<true>(h[t][3]));
         }
-        lin_S2<8, 2, 4, NTL>(w2p + (2 * c) * 128, hs, y);      // all 64 rows, hidden 64c..64c+63
+        lin_S2<8, 2, 4, NTL, bf_terms(SPL)>(w2p + (2 * c) * 128, hs, y);      // all 64 rows, hidden 64c..64c+63
       }
 #pragma unroll
       for (int t = 0; t < NTL; ++t) {
@@ -975,7 +975,7 @@ constexpr int qp_lds_floats(bool spl) {
 struct QpLds {
   float *W0, *W2, *b0, *b2;
 };
-template <bool SPL>
+template <int SPL>
 __device__ __forceinline__ QpLds qp_lds() {
   QpLds L;
   L.W0 = smem;
@@ -984,7 +984,7 @@ __device__ __forceinline__ QpLds qp_lds() {
   L.b2 = L.b0 + 64;
   return L;
 }
-template <bool SPL, int TPB>
+template <int SPL, int TPB>
 struct QpStager {  // (see FfStager)
   WStage<SPL, 64, 12, TPB> s0;
   WStage<SPL, 64, 4, TPB> s2;
@@ -998,14 +998,14 @@ struct QpStager {  // (see FfStager)
     v0.store(L.b0, tid), v2.store(L.b2, tid);
   }
 };
-template <bool SPL, int TPB>
+template <int SPL, int TPB>
 __device__ __forceinline__ void qp_stage(const QpLds& L, const gpn_linear_t& fc0, const gpn_linear_t& fc2, int tid) {
   QpStager<SPL, TPB> st;
   st.load(fc0, fc2, tid);
   st.store(L, tid);
 }
 // the MLP on a wave's tiles u = 0 .. nu-1 (`pt` as in ff_run); q_in and q_out may be the same array
-template <bool SPL, class PT>
+template <int SPL, class PT>
 __device__ __forceinline__ void qp_run(const QpLds& L, const float* q_in, const float* __restrict__ emb_pt,
                                        const float* __restrict__ emb_ray, int S, float* q_out, long long nu, int lane,
                                        PT&& pt) {
@@ -1029,7 +1029,7 @@ __device__ __forceinline__ void qp_run(const QpLds& L, const float* q_in, const 
     lin<SPL, 12, 4>(L.W0, QP_LD0, x, h, lane);
 #pragma unroll
     for (int M = 0; M < 4; ++M) {
-      h[M] = f4_relu_t<SPL>(h[M]);
+      h[M] = f4_relu_t<(SPL != 0)>(h[M]);
       y[M] = ld4(L.b2 + 16 * M + 4 * g);
     }
     lin<SPL, 4, 4>(L.W2, LDW, h, y, lane);
@@ -1042,7 +1042,7 @@ __device__ __forceinline__ void qp_run(const QpLds& L, const float* q_in, const 
 
 // second phase of an attention kernel (ff_out != nullptr): the layer's feed-forward block on the tiles this
 // workgroup has just written, after re-staging LDS with the FF weights
-template <bool SPL, int TPB, class PT>
+template <int SPL, int TPB, class PT>
 __device__ __forceinline__ void ff_phase(const float* __restrict__ norm_w, const float* __restrict__ norm_b,
                                          const gpn_linear_t& fc1, const gpn_linear_t& fc2, const float* x, float* ff_out,
                                          long long nu, int tid, PT&& pt) {
@@ -1050,7 +1050,7 @@ __device__ __forceinline__ void ff_phase(const float* __restrict__ norm_w, const
   const FfLds F = ff_lds<SPL>();
   f4 xpre[FF_NTL][4];
   // this wave's own stores of x are in program order before these loads
-  if constexpr (SPL)  // ff_run<REV> starts at the last iteration
+  if constexpr (SPL != 0)  // ff_run<REV> starts at the last iteration
     ff_prefetch(xpre, x, nu > 0 ? (nu + FF_NTL - 1) / FF_NTL * FF_NTL - FF_NTL : 0, lane, pt);
   FfStager<SPL, TPB> st;
   st.load(norm_w, norm_b, fc1, fc2, tid);  // in flight across the barrier
@@ -1062,7 +1062,7 @@ __device__ __forceinline__ void ff_phase(const float* __restrict__ norm_w, const
 
 // third phase of k_view_attn on even layers (qp_out != nullptr): q = q_fcs[l](cat(q, emb_pt, emb_ray)) on the
 // same tiles, LDS re-staged once more
-template <bool SPL, int TPB, class PT>
+template <int SPL, int TPB, class PT>
 __device__ __forceinline__ void qp_phase(const gpn_linear_t& fc0, const gpn_linear_t& fc2, const float* q,
                                          const float* __restrict__ emb_pt, const float* __restrict__ emb_ray, int S,
                                          float* qp_out, long long nu, int tid, PT&& pt) {
@@ -1075,7 +1075,7 @@ __device__ __forceinline__ void qp_phase(const gpn_linear_t& fc0, const gpn_line
   qp_run<SPL>(Q, q, emb_pt, emb_ray, S, qp_out, nu, tid & 63, pt);
 }
 
-template <bool SPL, bool FOLD, bool TILED = false>
+template <int SPL, bool FOLD, bool TILED = false>
 __global__ void __launch_bounds__(VA_TPB)
 k_view_attn(gpn_view_layer_t Lw, const float* q_in, const float* __restrict__ feat,
             const float* __restrict__ ray_diff, const float* __restrict__ mask,
@@ -1426,20 +1426,20 @@ k_view_attn(gpn_view_layer_t Lw, const float* q_in, const float* __restrict__ fe
           a[M] = ld4(L.bA2 + 16 * M + 4 * g);
         }
         // pos hidden layer: 4 -> 8 (ReLU), one fp32 MFMA
-        f4 ph = f4_relu_t<SPL>(mfma16(p0w, rd, ld4(L.bP0 + 4 * g)));
+        f4 ph = f4_relu_t<(SPL != 0)>(mfma16(p0w, rd, ld4(L.bP0 + 4 * g)));
         f4 ah;  // post-ReLU hidden layer of attn_fc: rows 4g..4g+3 of the (zero-padded) 16
-        if constexpr (FOLD && SPL) {
+        if constexpr (FOLD && SPL != 0) {
           // v + pos = (Wv Wk) f + P2 h + b ; attn hidden = (A0 Wk) f + (A0 P2) h + aq : every product
           // reads the split of f and h made once here
           XS xs[3];
           xs[0] = feat_pair(fcur[0], fcur[1]);
           xs[1] = feat_pair(fcur[2], fcur[3]);
           xs[2] = split8(ph, f4_zero());
-          lin_Sx<4, 4>(L.Wv, xs, vp, lane);
-          lin_Sx<1, 4>(L.P2, xs + 2, vp, lane);
+          lin_Sx<4, 4, true, bf_terms(SPL)>(L.Wv, xs, vp, lane);
+          lin_Sx<1, 4, true, bf_terms(SPL)>(L.P2, xs + 2, vp, lane);
           ah = aq;
-          lin_Sx<6, 1>(L.AF, xs, &ah, lane);
-          ah = f4_relu_t<SPL>(ah);
+          lin_Sx<6, 1, true, bf_terms(SPL)>(L.AF, xs, &ah, lane);
+          ah = f4_relu_t<(SPL != 0)>(ah);
           lin<SPL, 1, 4>(L.A2, VA_LD8, &ah, a, lane);
         } else if constexpr (FOLD) {
           // the same two chains on fp32 MFMAs: 117 instead of 177 MFMAs per (tile, view) -- k is never formed
@@ -1448,15 +1448,15 @@ k_view_attn(gpn_view_layer_t Lw, const float* q_in, const float* __restrict__ fe
           lin_T<1, 4>(L.P2, VA_LD8, &ph, vp, lane);
           ah = aq;
           lin_T<5, 1>(L.AF, VA_LDAF, xin, &ah, lane);
-          ah = f4_relu_t<SPL>(ah);
+          ah = f4_relu_t<(SPL != 0)>(ah);
           lin_T<1, 4>(L.A2, VA_LD8, &ah, a, lane);
         } else {
           f4 k[4];
 #pragma unroll
           for (int M = 0; M < 4; ++M) k[M] = f4_zero();
-          if constexpr (SPL) {
+          if constexpr (SPL != 0) {
             const XS xf[2] = {feat_pair(fcur[0], fcur[1]), feat_pair(fcur[2], fcur[3])};
-            lin_Sx<4, 4>(L.Wk, xf, k, lane);
+            lin_Sx<4, 4, true, bf_terms(SPL)>(L.Wk, xf, k, lane);
           } else {
             lin_T<4, 4>(L.Wk, LDW, fcur, k, lane);   // k = k_fc(feat)
           }
@@ -1475,7 +1475,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* q_in, const float* __restrict__ fe
           for (int M = 0; M < 4; ++M) vp[M] = vp[M] + pos[M];
           ah = ld4(L.bA0 + 4 * g);
           lin<SPL, 4, 1>(L.A0, LDW, ain, &ah, lane);
-          ah = f4_relu_t<SPL>(ah);
+          ah = f4_relu_t<(SPL != 0)>(ah);
           lin<SPL, 1, 4>(L.A2, VA_LD8, &ah, a, lane);
         }
         if (MODE == VM_HOMOG) VA_MARK(3);
@@ -1624,7 +1624,7 @@ k_view_attn(gpn_view_layer_t Lw, const float* q_in, const float* __restrict__ fe
 }
 
 // ------------------------------------------------------------------------------------ feed-forward (kernel)
-template <bool SPL>
+template <int SPL>
 __global__ void __launch_bounds__(FF_TPB)
 k_ff(const float* __restrict__ norm_w, const float* __restrict__ norm_b, gpn_linear_t fc1,
      gpn_linear_t fc2, const float* x_in, long long N, float* x_out) {
@@ -1640,7 +1640,7 @@ k_ff(const float* __restrict__ norm_w, const float* __restrict__ norm_b, gpn_lin
   const long long nu = SPL ? ff_tile_count(ntiles, w0 * FF_NTL, stride * FF_NTL)
                            : (w0 < ntiles ? (ntiles - w0 + stride - 1) / stride : 0);
   f4 xpre[FF_NTL][4];
-  if constexpr (SPL) ff_prefetch(xpre, x_in, 0, lane, pt);
+  if constexpr (SPL != 0) ff_prefetch(xpre, x_in, 0, lane, pt);
   ff_stage<SPL, FF_TPB>(L, norm_w, norm_b, fc1, fc2, tid);
   __syncthreads();
   STAMP(10);
@@ -1836,7 +1836,7 @@ k_ff32(const float* __restrict__ norm_w, const float* __restrict__ norm_b, gpn_l
 }
 
 // ------------------------------------------------------------------------------------ q positional MLP (kernel)
-template <bool SPL>
+template <int SPL>
 __global__ void __launch_bounds__(QP_TPB)
 k_qpos(gpn_linear_t fc0, gpn_linear_t fc2, const float* q_in,
        const float* __restrict__ emb_pt, const float* __restrict__ emb_ray, long long N, int S,
@@ -1888,7 +1888,7 @@ struct RayCfg {
 //   Vt: unit (channel 16h+j, key tile kt, g) = keys 16kt+4g..+3           at (NT*h + kt)*64 + 16g + j
 // so that one unit is the A operand of both MFMAs of a product: against B = [x_hi | x_hi] it yields
 // a_hi*x_hi + a_mid*x_hi, against B = [x_mid | 0] it yields a_hi*x_mid.
-template <int NT, bool SPL>
+template <int NT, int SPL>
 __global__ void __launch_bounds__(RayCfg<NT>::THREADS)
 k_ray_attn(gpn_ray_layer_t Lw, const float* x_in, int R, int S,
            float* x_out, float* __restrict__ abar, int abar_ld,
@@ -1956,17 +1956,17 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* x_in, int R, int S,
     layernorm_T(x, xn, gam, bet, 1e-6f, lane);
 #pragma unroll
     for (int M = 0; M < 4; ++M) qT[M] = f4_zero();
-    if constexpr (SPL) {
+    if constexpr (SPL != 0) {
       XS xs[2] = {split8(xn[0], xn[1]), split8(xn[2], xn[3])};
-      lin_Sx<4, 4>(Wq, xs, qT, lane);
+      lin_Sx<4, 4, true, bf_terms(SPL)>(Wq, xs, qT, lane);
       f4 kT[4], vN[4];
 #pragma unroll
       for (int M = 0; M < 4; ++M) kT[M] = f4_zero(), vN[M] = f4_zero();
-      lin_Sx<4, 4>(Wk, xs, kT, lane);
+      lin_Sx<4, 4, true, bf_terms(SPL)>(Wk, xs, kT, lane);
 #pragma unroll
       for (int M = 0; M < 4; ++M) Ku_s[(4 * t + M) * 64 + lane] = split4(kT[M]);
       // V in normal orientation: lane (j, g) holds V[key 16t + 4g + reg][channel 16M + j]
-      lin_Sx<4, 4, false>(Wv, xs, vN, lane);
+      lin_Sx<4, 4, false, bf_terms(SPL)>(Wv, xs, vN, lane);
 #pragma unroll
       for (int M = 0; M < 4; ++M) Vu_s[(NT * M + t) * 64 + lane] = split4(vN[M]);
     } else {
@@ -2010,19 +2010,19 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* x_in, int R, int S,
       // S^T tile: rows = keys, columns (lanes) = this wave's 16 queries; k-dim = the head's 16 channels
       f4 sT[NT];
       auto scores = [&]() {
-        if constexpr (SPL) {
+        if constexpr (SPL != 0) {
           const bf8 qs = split4(qT[h]);
           bf8 qb1, qb2;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            qb1[e] = qs[e], qb1[4 + e] = qs[e];
+            qb1[e] = qs[e], qb1[4 + e] = SPL == 2 ? (__bf16)0.0f : qs[e];  // plain bf16: k_hi * q_hi only
             qb2[e] = qs[4 + e], qb2[4 + e] = (__bf16)0.0f;
           }
           bf8 ku[NT];
 #pragma unroll
           for (int kt = 0; kt < NT; ++kt) ku[kt] = Ku_s[(4 * kt + h) * 64 + lane];
 #pragma unroll
-          for (int kt = 0; kt < NT; ++kt) sT[kt] = mfma_bf(ku[kt], qb2, f4_zero());
+          for (int kt = 0; kt < NT; ++kt) sT[kt] = SPL == 2 ? f4_zero() : mfma_bf(ku[kt], qb2, f4_zero());
 #pragma unroll
           for (int kt = 0; kt < NT; ++kt) sT[kt] = mfma_bf(ku[kt], qb1, sT[kt]);
         } else {
@@ -2101,7 +2101,7 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* x_in, int R, int S,
       }
       // O^T[h] = V_h^T . P^T : A = V (channels of head h on rows), B = P^T (keys in registers)
       f4 o0 = f4_zero(), o1 = f4_zero();
-      if constexpr (SPL) {
+      if constexpr (SPL != 0) {
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
           const bf8 vu = Vu_s[(NT * h + kt) * 64 + lane];
@@ -2109,11 +2109,16 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* x_in, int R, int S,
           bf8 pb1, pb2;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            pb1[e] = ps[e], pb1[4 + e] = ps[e];
+            pb1[e] = ps[e], pb1[4 + e] = SPL == 2 ? (__bf16)0.0f : ps[e];  // plain bf16: v_hi * p_hi only
             pb2[e] = ps[4 + e], pb2[4 + e] = (__bf16)0.0f;
           }
-          if ((kt & 1) == 0) o0 = mfma_bf(vu, pb1, mfma_bf(vu, pb2, o0));
-          else o1 = mfma_bf(vu, pb1, mfma_bf(vu, pb2, o1));
+          if constexpr (SPL == 2) {
+            if ((kt & 1) == 0) o0 = mfma_bf(vu, pb1, o0);
+            else o1 = mfma_bf(vu, pb1, o1);
+          } else {
+            if ((kt & 1) == 0) o0 = mfma_bf(vu, pb1, mfma_bf(vu, pb2, o0));
+            else o1 = mfma_bf(vu, pb1, mfma_bf(vu, pb2, o1));
+          }
         }
       } else {
 #pragma unroll
@@ -2197,7 +2202,7 @@ k_ray_attn(gpn_ray_layer_t Lw, const float* x_in, int R, int S,
 // weight images | bO gamma beta | per wave: the attention row of query 0 of every head (for `weights`)
 constexpr int ray1_lds_floats(bool spl) { return 4 * wimg_floats(spl, 64, 4, LDW) + 3 * 64 + RAY1_WAVES * 4 * 64; }
 
-template <int NT, bool SPL>
+template <int NT, int SPL>
 __global__ void __launch_bounds__(RAY1_WAVES * 64, RAY1_MINW)
 k_ray1(gpn_ray_layer_t Lw, const float* x_in, int R, int S, float* x_out,
        float* __restrict__ abar, int abar_ld, float* __restrict__ weights, float* ff_out) {
@@ -2227,7 +2232,7 @@ k_ray1(gpn_ray_layer_t Lw, const float* x_in, int R, int S, float* x_out,
   for (int ray = blockIdx.x * RAY1_WAVES + wave; ray < R; ray += (int)gridDim.x * RAY1_WAVES) {
     const size_t rbase = (size_t)ray * S;
     // ---- keys and values of the whole ray, tile by tile, into registers
-    typedef typename std::conditional<SPL, bf8, f4>::type kv_t;
+    typedef typename std::conditional<(SPL != 0), bf8, f4>::type kv_t;
     kv_t kk[NT][4], vv[NT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -2239,10 +2244,10 @@ k_ray1(gpn_ray_layer_t Lw, const float* x_in, int R, int S, float* x_out,
       f4 kT[4], vN[4];
 #pragma unroll
       for (int M = 0; M < 4; ++M) kT[M] = f4_zero(), vN[M] = f4_zero();
-      if constexpr (SPL) {
+      if constexpr (SPL != 0) {
         XS xs[2] = {split8(xn[0], xn[1]), split8(xn[2], xn[3])};
-        lin_Sx<4, 4>(Wk, xs, kT, lane);
-        lin_Sx<4, 4, false>(Wv, xs, vN, lane);
+        lin_Sx<4, 4, true, bf_terms(SPL)>(Wk, xs, kT, lane);
+        lin_Sx<4, 4, false, bf_terms(SPL)>(Wv, xs, vN, lane);
 #pragma unroll
         for (int M = 0; M < 4; ++M) kk[t][M] = split4(kT[M]), vv[t][M] = split4(vN[M]);
       } else {
@@ -2270,9 +2275,9 @@ k_ray1(gpn_ray_layer_t Lw, const float* x_in, int R, int S, float* x_out,
       layernorm_T(x, xn, gam, bet, 1e-6f, lane);
 #pragma unroll
       for (int M = 0; M < 4; ++M) qT[M] = f4_zero();
-      if constexpr (SPL) {
+      if constexpr (SPL != 0) {
         XS xs[2] = {split8(xn[0], xn[1]), split8(xn[2], xn[3])};
-        lin_Sx<4, 4>(Wq, xs, qT, lane);
+        lin_Sx<4, 4, true, bf_terms(SPL)>(Wq, xs, qT, lane);
       } else {
         lin_T<4, 4>(Wq, LDW, xn, qT, lane);
       }
@@ -2284,16 +2289,16 @@ k_ray1(gpn_ray_layer_t Lw, const float* x_in, int R, int S, float* x_out,
       for (int h = 0; h < 4; ++h) {
         f4 sT[NT];
         auto scores = [&]() {
-          if constexpr (SPL) {
+          if constexpr (SPL != 0) {
             const bf8 qs = split4(qT[h]);
             bf8 qb1, qb2;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              qb1[e] = qs[e], qb1[4 + e] = qs[e];
+              qb1[e] = qs[e], qb1[4 + e] = SPL == 2 ? (__bf16)0.0f : qs[e];  // plain bf16: k_hi * q_hi only
               qb2[e] = qs[4 + e], qb2[4 + e] = (__bf16)0.0f;
             }
 #pragma unroll
-            for (int kt = 0; kt < NT; ++kt) sT[kt] = mfma_bf(kk[kt][h], qb2, f4_zero());
+            for (int kt = 0; kt < NT; ++kt) sT[kt] = SPL == 2 ? f4_zero() : mfma_bf(kk[kt][h], qb2, f4_zero());
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) sT[kt] = mfma_bf(kk[kt][h], qb1, sT[kt]);
           } else {
@@ -2356,18 +2361,23 @@ k_ray1(gpn_ray_layer_t Lw, const float* x_in, int R, int S, float* x_out,
           }
         }
         f4 o0 = f4_zero(), o1 = f4_zero();
-        if constexpr (SPL) {
+        if constexpr (SPL != 0) {
 #pragma unroll
           for (int kt = 0; kt < NT; ++kt) {
             const bf8 ps = split4(sT[kt]);
             bf8 pb1, pb2;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              pb1[e] = ps[e], pb1[4 + e] = ps[e];
+              pb1[e] = ps[e], pb1[4 + e] = SPL == 2 ? (__bf16)0.0f : ps[e];  // plain bf16: v_hi * p_hi only
               pb2[e] = ps[4 + e], pb2[4 + e] = (__bf16)0.0f;
             }
-            if ((kt & 1) == 0) o0 = mfma_bf(vv[kt][h], pb1, mfma_bf(vv[kt][h], pb2, o0));
-            else o1 = mfma_bf(vv[kt][h], pb1, mfma_bf(vv[kt][h], pb2, o1));
+            if constexpr (SPL == 2) {
+              if ((kt & 1) == 0) o0 = mfma_bf(vv[kt][h], pb1, o0);
+              else o1 = mfma_bf(vv[kt][h], pb1, o1);
+            } else {
+              if ((kt & 1) == 0) o0 = mfma_bf(vv[kt][h], pb1, mfma_bf(vv[kt][h], pb2, o0));
+              else o1 = mfma_bf(vv[kt][h], pb1, mfma_bf(vv[kt][h], pb2, o1));
+            }
           }
         } else {
 #pragma unroll
@@ -2801,6 +2811,16 @@ k_sem_adaptor(gpn_linear_t fc, const float* __restrict__ pre, int R, float* __re
 
 // ==================================================================================== C-ABI
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// f(std::integral_constant<int, GPN_PREC_*>) for the arithmetic mode `precision` (validated by GPN_REQUIRE_PREC):
+// every GNT kernel is a template over the mode
+template <class F>
+static int by_precision(int precision, F&& f) {
+  switch (precision) {
+    case GPN_PREC_BF16X3: return f(std::integral_constant<int, GPN_PREC_BF16X3>{});
+    case GPN_PREC_BF16: return f(std::integral_constant<int, GPN_PREC_BF16>{});
+    default: return f(std::integral_constant<int, GPN_PREC_FP32>{});
+  }
+}
 #define REQ_LIN(l, name) \
   GPN_REQUIRE((l).w && aligned16((l).w), "%s: weight pointer null or not 16-byte aligned", name)
 
@@ -2834,16 +2854,15 @@ extern "C" int gpn_rgbfeat(const gpn_linear_t* fc0, const gpn_linear_t* fc2, con
   GPN_REQUIRE((in_ld & 3) != 0 || aligned16(rgb_feat),
               "gpn_rgbfeat: rgb_feat with rows of a multiple of 4 floats must be 16-byte aligned");
   GPN_REQUIRE_INT_RANGE(N, 1, V, "gpn_rgbfeat");
-  const bool spl = precision == GPN_PREC_BF16X3;
+  const bool spl = precision != GPN_PREC_FP32;
   const size_t lds = sizeof(float) * (wimg_floats(spl, 64, 3, RF_LD0) + wimg_floats(spl, 64, 4, LDW) + 128);
   const int grid = persistent_grid(((long long)N + (RF_TPB / 4) - 1) / (RF_TPB / 4), GPN_MEM_BPC);
   GpnStageTimer timer_k_rgbfeat_(GPN_ST_RGBFEAT, (hipStream_t)stream);
-  if (spl)
-    hipLaunchKernelGGL(k_rgbfeat<true>, dim3(grid), dim3(RF_TPB), lds, (hipStream_t)stream, *fc0, *fc2,
+  by_precision(precision, [&](auto m) {
+    hipLaunchKernelGGL(k_rgbfeat<decltype(m)::value>, dim3(grid), dim3(RF_TPB), lds, (hipStream_t)stream, *fc0, *fc2,
                        rgb_feat, (long long)N, V, in_ch, in_ld, mask, feat, q0);
-  else
-    hipLaunchKernelGGL(k_rgbfeat<false>, dim3(grid), dim3(RF_TPB), lds, (hipStream_t)stream, *fc0, *fc2,
-                       rgb_feat, (long long)N, V, in_ch, in_ld, mask, feat, q0);
+    return 0;
+  });
   GPN_LAUNCH_CHECK("k_rgbfeat");
   return GPN_OK;
 }
@@ -2879,19 +2898,19 @@ static int proj_rgbfeat_launch(const gpn_project_args_t* a, const gpn_linear_t* 
   REQ_LIN(*fc2, "gpn_project_rgbfeat.fc2");
   GPN_REQUIRE(aligned16(feat) && aligned16(q0) && aligned16(a->feat) && (!a->ray_diff || aligned16(a->ray_diff)),
               "gpn_project_rgbfeat: feat, q0, the feature maps and ray_diff must be 16-byte aligned");
-  const bool spl = precision == GPN_PREC_BF16X3;
+  const bool spl = precision != GPN_PREC_FP32;
   const size_t lds = proj_rgbfeat_lds(spl);
-  int rc = set_lds_limit(spl ? reinterpret_cast<const void*>(k_proj_rgbfeat<true>)
-                             : reinterpret_cast<const void*>(k_proj_rgbfeat<false>), lds);
-  if (rc) return rc;
   const int grid = persistent_grid(((long long)a->N + (PR_TPB / 4) - 1) / (PR_TPB / 4), PR_BPC);
-  GpnStageTimer timer_(GPN_ST_PROJ_RGBFEAT, (hipStream_t)stream);
-  if (spl)
-    hipLaunchKernelGGL(k_proj_rgbfeat<true>, dim3(grid), dim3(PR_TPB), lds, (hipStream_t)stream, *a, *fc0, *fc2,
+  int rc = by_precision(precision, [&](auto m) {
+    constexpr int M = decltype(m)::value;
+    int rc_ = set_lds_limit(reinterpret_cast<const void*>(k_proj_rgbfeat<M>), lds);
+    if (rc_) return rc_;
+    GpnStageTimer timer_(GPN_ST_PROJ_RGBFEAT, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_proj_rgbfeat<M>, dim3(grid), dim3(PR_TPB), lds, (hipStream_t)stream, *a, *fc0, *fc2,
                        feat, q0, perm, rdp, tiled);
-  else
-    hipLaunchKernelGGL(k_proj_rgbfeat<false>, dim3(grid), dim3(PR_TPB), lds, (hipStream_t)stream, *a, *fc0, *fc2,
-                       feat, q0, perm, rdp, tiled);
+    return 0;
+  });
+  if (rc) return rc;
   GPN_LAUNCH_CHECK("k_proj_rgbfeat");
   return GPN_OK;
 }
@@ -2969,7 +2988,7 @@ static int view_attn_launch(const gpn_view_layer_t* L, const float* q_in, const 
   GPN_REQUIRE(!stats || (stats_ld >= C64 && stats_ld % 4 == 0),
               "gpn_view_attn: stats_ld must be a multiple of 4 and >= %d (got %d)", C64, stats_ld);
   GPN_REQUIRE_INT_RANGE(N, 1, V, "gpn_view_attn");
-  const bool spl = precision == GPN_PREC_BF16X3;
+  const bool spl = precision != GPN_PREC_FP32;
   const bool fold = L->folded != nullptr;
   // the launch's dynamic LDS must hold the largest image of its phases: attention weights + DMA ring, the
   // feed-forward weights, the q-MLP weights (the later phases re-stage from the base of the same allocation)
@@ -2990,36 +3009,24 @@ static int view_attn_launch(const gpn_view_layer_t* L, const float* q_in, const 
   GPN_REQUIRE(qp_out == nullptr || (ff_out && qfc0 && qfc2 && qfc0->w && qfc2->w && emb_pt && emb_ray && S >= 1),
               "gpn_view_attn: fused q MLP needs the feed-forward phase, its weights and the encodings");
   const gpn_linear_t q0_ = qp_out ? *qfc0 : gpn_linear_t{}, q2_ = qp_out ? *qfc2 : gpn_linear_t{};
-  const void* fn = tiled ? (spl ? reinterpret_cast<const void*>(k_view_attn<true, true, true>)
-                                : reinterpret_cast<const void*>(k_view_attn<false, true, true>))
-                   : spl ? (fold ? reinterpret_cast<const void*>(k_view_attn<true, true>)
-                                 : reinterpret_cast<const void*>(k_view_attn<true, false>))
-                         : (fold ? reinterpret_cast<const void*>(k_view_attn<false, true>)
-                                 : reinterpret_cast<const void*>(k_view_attn<false, false>));
-  int rc = set_lds_limit(fn, lds);
-  if (rc) return rc;
   const int grid = persistent_grid(((long long)N + (VA_TPB / 4) - 1) / (VA_TPB / 4));
-  GpnStageTimer timer_k_view_attn_(GPN_ST_VIEW_ATTN, (hipStream_t)stream);
   const dim3 g3(grid), b3(VA_TPB);
   hipStream_t st = (hipStream_t)stream;
-  if (tiled && spl)
-    hipLaunchKernelGGL((k_view_attn<true, true, true>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
-                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, layout, ff_out, q0_, q2_, emb_pt, emb_ray, S, qp_out);
-  else if (tiled)
-    hipLaunchKernelGGL((k_view_attn<false, true, true>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
-                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, layout, ff_out, q0_, q2_, emb_pt, emb_ray, S, qp_out);
-  else if (fold && spl)
-    hipLaunchKernelGGL((k_view_attn<true, true>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
-                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, layout, ff_out, q0_, q2_, emb_pt, emb_ray, S, qp_out);
-  else if (fold)
-    hipLaunchKernelGGL((k_view_attn<false, true>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
-                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, layout, ff_out, q0_, q2_, emb_pt, emb_ray, S, qp_out);
-  else if (spl)
-    hipLaunchKernelGGL((k_view_attn<true, false>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
-                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, layout, ff_out, q0_, q2_, emb_pt, emb_ray, S, qp_out);
-  else
-    hipLaunchKernelGGL((k_view_attn<false, false>), g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm,
-                       (long long)N, V, q_out, hidden, hidden_ld, stats, stats_ld, layout, ff_out, q0_, q2_, emb_pt, emb_ray, S, qp_out);
+  auto go = [&](auto kernel) {
+    int rc_ = set_lds_limit(reinterpret_cast<const void*>(kernel), lds);
+    if (rc_) return rc_;
+    GpnStageTimer timer_k_view_attn_(GPN_ST_VIEW_ATTN, st);
+    hipLaunchKernelGGL(kernel, g3, b3, lds, st, *L, q_in, feat, ray_diff, mask, perm, (long long)N, V, q_out, hidden,
+                       hidden_ld, stats, stats_ld, layout, ff_out, q0_, q2_, emb_pt, emb_ray, S, qp_out);
+    return 0;
+  };
+  int rc = by_precision(precision, [&](auto m) {
+    constexpr int M = decltype(m)::value;
+    if (tiled) return go(k_view_attn<M, true, true>);
+    if (fold) return go(k_view_attn<M, true>);
+    return go(k_view_attn<M, false>);
+  });
+  if (rc) return rc;
   GPN_LAUNCH_CHECK("k_view_attn");
   return GPN_OK;
 }
@@ -3057,25 +3064,29 @@ extern "C" int gpn_ff(const float* norm_w, const float* norm_b, const gpn_linear
   REQ_LIN(*fc2, "gpn_ff.fc2");
   GPN_REQUIRE(aligned16(x_in) && aligned16(x_out), "gpn_ff: tensors must be 16-byte aligned");
   GPN_REQUIRE(N >= 0, "gpn_ff: bad N");
-  const bool spl = precision == GPN_PREC_BF16X3;
+  const bool spl = precision != GPN_PREC_FP32;
   const size_t lds = sizeof(float) * ff_lds_floats(spl);
-  int rc = set_lds_limit(spl ? reinterpret_cast<const void*>(k_ff<true>)
-                             : reinterpret_cast<const void*>(k_ff<false>), lds);
-  if (rc) return rc;
   const int grid = persistent_grid(((long long)N + (FF_TPB / 4) - 1) / (FF_TPB / 4));
-  GpnStageTimer timer_k_ff_(GPN_ST_FF, (hipStream_t)stream);
-  if (spl && GPN_FF32) {
+  int rc = 0;
+  if (precision == GPN_PREC_BF16X3 && GPN_FF32) {
     rc = set_lds_limit(reinterpret_cast<const void*>(k_ff32), lds);
     if (rc) return rc;
+    GpnStageTimer timer_k_ff_(GPN_ST_FF, (hipStream_t)stream);
     const int grid32 = persistent_grid(((long long)N + (FF_TPB / 2) - 1) / (FF_TPB / 2));
     hipLaunchKernelGGL(k_ff32, dim3(grid32), dim3(FF_TPB), lds, (hipStream_t)stream, norm_w, norm_b, *fc1,
                        *fc2, x_in, (long long)N, x_out);
-  } else if (spl)
-    hipLaunchKernelGGL(k_ff<true>, dim3(grid), dim3(FF_TPB), lds, (hipStream_t)stream, norm_w, norm_b, *fc1,
-                     *fc2, x_in, (long long)N, x_out);
-  else
-    hipLaunchKernelGGL(k_ff<false>, dim3(grid), dim3(FF_TPB), lds, (hipStream_t)stream, norm_w, norm_b, *fc1,
-                     *fc2, x_in, (long long)N, x_out);
+  } else {
+    rc = by_precision(precision, [&](auto m) {
+      constexpr int M = decltype(m)::value;
+      int rc_ = set_lds_limit(reinterpret_cast<const void*>(k_ff<M>), lds);
+      if (rc_) return rc_;
+      GpnStageTimer timer_k_ff_(GPN_ST_FF, (hipStream_t)stream);
+      hipLaunchKernelGGL(k_ff<M>, dim3(grid), dim3(FF_TPB), lds, (hipStream_t)stream, norm_w, norm_b, *fc1,
+                         *fc2, x_in, (long long)N, x_out);
+      return 0;
+    });
+    if (rc) return rc;
+  }
   GPN_LAUNCH_CHECK("k_ff");
   return GPN_OK;
 }
@@ -3091,24 +3102,24 @@ extern "C" int gpn_qpos(const gpn_linear_t* fc0, const gpn_linear_t* fc2, const 
   GPN_REQUIRE(aligned16(q_in) && aligned16(emb_pt) && aligned16(emb_ray) && aligned16(q_out),
               "gpn_qpos: tensors must be 16-byte aligned");
   GPN_REQUIRE(N >= 0 && S >= 1 && N % S == 0, "gpn_qpos: N must be a multiple of S >= 1 (got N=%d S=%d)", N, S);
-  const bool spl = precision == GPN_PREC_BF16X3;
+  const bool spl = precision != GPN_PREC_FP32;
   const size_t lds = sizeof(float) * qp_lds_floats(spl);
-  int rc = set_lds_limit(spl ? reinterpret_cast<const void*>(k_qpos<true>)
-                             : reinterpret_cast<const void*>(k_qpos<false>), lds);
-  if (rc) return rc;
   const int grid = persistent_grid(((long long)N + (QP_TPB / 4) - 1) / (QP_TPB / 4));
-  GpnStageTimer timer_k_qpos_(GPN_ST_QPOS, (hipStream_t)stream);
-  if (spl)
-    hipLaunchKernelGGL(k_qpos<true>, dim3(grid), dim3(QP_TPB), lds, (hipStream_t)stream, *fc0, *fc2, q_in, emb_pt,
-                     emb_ray, (long long)N, S, q_out);
-  else
-    hipLaunchKernelGGL(k_qpos<false>, dim3(grid), dim3(QP_TPB), lds, (hipStream_t)stream, *fc0, *fc2, q_in, emb_pt,
-                     emb_ray, (long long)N, S, q_out);
+  int rc = by_precision(precision, [&](auto m) {
+    constexpr int M = decltype(m)::value;
+    int rc_ = set_lds_limit(reinterpret_cast<const void*>(k_qpos<M>), lds);
+    if (rc_) return rc_;
+    GpnStageTimer timer_k_qpos_(GPN_ST_QPOS, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_qpos<M>, dim3(grid), dim3(QP_TPB), lds, (hipStream_t)stream, *fc0, *fc2, q_in, emb_pt,
+                       emb_ray, (long long)N, S, q_out);
+    return 0;
+  });
+  if (rc) return rc;
   GPN_LAUNCH_CHECK("k_qpos");
   return GPN_OK;
 }
 
-template <int NT, bool SPL>
+template <int NT, int SPL>
 static int launch_ray_attn_p(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,
                              float* abar, int abar_ld, float* weights, hipStream_t stream, float* ff_out_req) {
   // S > 64: k_ray_attn<5..8> has no registers to spare (the extra phase costs spills: measured on the
@@ -3119,16 +3130,16 @@ static int launch_ray_attn_p(const gpn_ray_layer_t* L, const float* x_in, int R,
     int rc0 = launch_ray_attn_p<NT, SPL>(L, x_in, R, S, x_out, abar, abar_ld, weights, stream, nullptr);
     if (rc0) return rc0;
     return gpn_ff(L->ff_norm_w, L->ff_norm_b, &L->ff1, &L->ff2, x_out, R * S, ff_out_req,
-                  SPL ? GPN_PREC_BF16X3 : GPN_PREC_FP32, (gpn_stream_t)stream);
+                  SPL, (gpn_stream_t)stream);
   }
   // (ff_out: the feed-forward phase re-stages LDS with its own weights: the launch needs the larger image)
-  const size_t lds_ff = ff_out ? sizeof(float) * ff_lds_floats(SPL) : 0;
+  const size_t lds_ff = ff_out ? sizeof(float) * ff_lds_floats(SPL != 0) : 0;
 #if GPN_RAY1
   // one wave per ray, keys / values in registers (k_ray1).  Per launch at R = 4096 (rocprofv3): S = 48 fp32
   // 111 -> 89 us, bf16x3 59 -> 52.5 us; S = 64 (the 128 key / value registers leave the compiler no room)
   // fp32 124.5 -> 125, bf16x3 68.5 -> 72 us: k_ray_attn stays the kernel of S > 48
   if constexpr (NT <= RAY1_MAXNT) {
-    const size_t lds1 = std::max(sizeof(float) * ray1_lds_floats(SPL), lds_ff);
+    const size_t lds1 = std::max(sizeof(float) * ray1_lds_floats(SPL != 0), lds_ff);
     int rc1 = set_lds_limit(reinterpret_cast<const void*>(k_ray1<NT, SPL>), lds1);
     if (rc1) return rc1;
     const int grid1 = persistent_grid(((long long)R + RAY1_WAVES - 1) / RAY1_WAVES);
@@ -3155,9 +3166,9 @@ template <int NT>
 static int launch_ray_attn(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,
                            float* abar, int abar_ld, float* weights, int precision, hipStream_t stream,
                            float* ff_out) {
-  if (precision == GPN_PREC_BF16X3)
-    return launch_ray_attn_p<NT, true>(L, x_in, R, S, x_out, abar, abar_ld, weights, stream, ff_out);
-  return launch_ray_attn_p<NT, false>(L, x_in, R, S, x_out, abar, abar_ld, weights, stream, ff_out);
+  return by_precision(precision, [&](auto m) {
+    return launch_ray_attn_p<NT, decltype(m)::value>(L, x_in, R, S, x_out, abar, abar_ld, weights, stream, ff_out);
+  });
 }
 
 static int ray_attn_launch(const gpn_ray_layer_t* L, const float* x_in, int R, int S, float* x_out,

@@ -343,7 +343,7 @@ __device__ __forceinline__ void store_feat_split(float* row, const f4* y, int g)
 }
 // Row -> registers: fp32 mode, the four T-tiles; split mode, f[2P] = hi and f[2P+1] = mid of K pair P
 // (raw 16-byte units held in f4 registers).  Both modes: f[k] = the 16 bytes at 64 k + 16 g.
-template <bool SP>
+template <int SP>
 __device__ __forceinline__ void load_feat_row(const float* row, int g, f4* f) {
 #pragma unroll
   for (int T = 0; T < 4; ++T) f[T] = ld4(row + 16 * T + 4 * g);
@@ -374,8 +374,11 @@ __device__ __forceinline__ bf8 split4(f4 a) {
 // y[M] += W . x in split mode on pre-split activations xs[(KT+1)/2].  TRANSPOSED = true keeps the
 // T-tile orientation of lin_T (weights are the A operand); false swaps the operands, so the result
 // comes out in normal orientation: lane (j, g) holds Y[point 4g + reg][channel 16M + j].
-template <int KT, int MT, bool TRANSPOSED = true>
+// TERMS = 3: the three-term split product (GPN_PREC_BF16X3); TERMS = 1: w_hi * x_hi only (GPN_PREC_BF16, plain
+// bf16 operands with fp32 accumulation: the mid pieces of the images / splits are then dead and never computed).
+template <int KT, int MT, bool TRANSPOSED = true, int TERMS = 3>
 __device__ __forceinline__ void lin_Sx(const float* Wf, const XS* xs, f4* y, int lane) {
+  static_assert(TERMS == 1 || TERMS == 3, "TERMS: 1 (plain bf16) or 3 (bf16x3)");
   constexpr int KP = (KT + 1) / 2;
   const bf8* wp = reinterpret_cast<const bf8*>(Wf) + lane;
   constexpr int MC = MT < 4 ? MT : 4;
@@ -386,7 +389,7 @@ __device__ __forceinline__ void lin_Sx(const float* Wf, const XS* xs, f4* y, int
 #pragma unroll
     for (int m = 0; m < MC; ++m) {
       wh[m] = wp[((M0 + m) * KP) * 128];
-      wm[m] = wp[((M0 + m) * KP) * 128 + 64];
+      if constexpr (TERMS == 3) wm[m] = wp[((M0 + m) * KP) * 128 + 64];
     }
 #pragma unroll
     for (int P = 0; P < KP; ++P) {
@@ -395,22 +398,26 @@ __device__ __forceinline__ void lin_Sx(const float* Wf, const XS* xs, f4* y, int
 #pragma unroll
         for (int m = 0; m < MC; ++m) {
           nh[m] = wp[((M0 + m) * KP + P + 1) * 128];
-          nm[m] = wp[((M0 + m) * KP + P + 1) * 128 + 64];
+          if constexpr (TERMS == 3) nm[m] = wp[((M0 + m) * KP + P + 1) * 128 + 64];
         }
       }
       // small terms first, so that they are not rounded away against the large one
       if constexpr (TRANSPOSED) {
+        if constexpr (TERMS == 3) {
 #pragma unroll
-        for (int m = 0; m < MC; ++m) y[M0 + m] = mfma_bf(wm[m], xs[P].hi, y[M0 + m]);
+          for (int m = 0; m < MC; ++m) y[M0 + m] = mfma_bf(wm[m], xs[P].hi, y[M0 + m]);
 #pragma unroll
-        for (int m = 0; m < MC; ++m) y[M0 + m] = mfma_bf(wh[m], xs[P].mid, y[M0 + m]);
+          for (int m = 0; m < MC; ++m) y[M0 + m] = mfma_bf(wh[m], xs[P].mid, y[M0 + m]);
+        }
 #pragma unroll
         for (int m = 0; m < MC; ++m) y[M0 + m] = mfma_bf(wh[m], xs[P].hi, y[M0 + m]);
       } else {
+        if constexpr (TERMS == 3) {
 #pragma unroll
-        for (int m = 0; m < MC; ++m) y[M0 + m] = mfma_bf(xs[P].hi, wm[m], y[M0 + m]);
+          for (int m = 0; m < MC; ++m) y[M0 + m] = mfma_bf(xs[P].hi, wm[m], y[M0 + m]);
 #pragma unroll
-        for (int m = 0; m < MC; ++m) y[M0 + m] = mfma_bf(xs[P].mid, wh[m], y[M0 + m]);
+          for (int m = 0; m < MC; ++m) y[M0 + m] = mfma_bf(xs[P].mid, wh[m], y[M0 + m]);
+        }
 #pragma unroll
         for (int m = 0; m < MC; ++m) y[M0 + m] = mfma_bf(xs[P].hi, wh[m], y[M0 + m]);
       }
@@ -419,7 +426,10 @@ __device__ __forceinline__ void lin_Sx(const float* Wf, const XS* xs, f4* y, int
 #endif
       if (P + 1 < KP) {
 #pragma unroll
-        for (int m = 0; m < MC; ++m) wh[m] = nh[m], wm[m] = nm[m];
+        for (int m = 0; m < MC; ++m) {
+          wh[m] = nh[m];
+          if constexpr (TERMS == 3) wm[m] = nm[m];
+        }
       }
     }
   }
@@ -429,13 +439,13 @@ __device__ __forceinline__ void lin_Sx(const float* Wf, const XS* xs, f4* y, int
 // for t = 0, 1.  Every weight unit read from LDS feeds two MFMAs (half the LDS traffic per flop of
 // lin_Sx) and the two tiles give the MFMA pipe two independent dependency chains.
 // wp = image base + lane + (M0*KPT + P0)*128 units, KPT = K pairs of the whole image.
-template <int KPT, int NP, int MT, int NTL = 2>
+template <int KPT, int NP, int MT, int NTL = 2, int TERMS = 3>
 __device__ __forceinline__ void lin_S2(const bf8* wp, const XS (&xs)[NTL][NP], f4 (&y)[NTL][MT]) {
   bf8 wh[MT], wm[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     wh[m] = wp[(m * KPT) * 128];
-    wm[m] = wp[(m * KPT) * 128 + 64];
+    if constexpr (TERMS == 3) wm[m] = wp[(m * KPT) * 128 + 64];
   }
 #pragma unroll
   for (int P = 0; P < NP; ++P) {
@@ -444,17 +454,19 @@ __device__ __forceinline__ void lin_S2(const bf8* wp, const XS (&xs)[NTL][NP], f
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         nh[m] = wp[(m * KPT + P + 1) * 128];
-        nm[m] = wp[(m * KPT + P + 1) * 128 + 64];
+        if constexpr (TERMS == 3) nm[m] = wp[(m * KPT + P + 1) * 128 + 64];
       }
     }
+    if constexpr (TERMS == 3) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int t = 0; t < NTL; ++t) y[t][m] = mfma_bf(wm[m], xs[t][P].hi, y[t][m]);
+        for (int t = 0; t < NTL; ++t) y[t][m] = mfma_bf(wm[m], xs[t][P].hi, y[t][m]);
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int t = 0; t < NTL; ++t) y[t][m] = mfma_bf(wh[m], xs[t][P].mid, y[t][m]);
+        for (int t = 0; t < NTL; ++t) y[t][m] = mfma_bf(wh[m], xs[t][P].mid, y[t][m]);
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -462,24 +474,31 @@ __device__ __forceinline__ void lin_S2(const bf8* wp, const XS (&xs)[NTL][NP], f
     __builtin_amdgcn_sched_barrier(0);
     if (P + 1 < NP) {
 #pragma unroll
-      for (int m = 0; m < MT; ++m) wh[m] = nh[m], wm[m] = nm[m];
+      for (int m = 0; m < MT; ++m) {
+        wh[m] = nh[m];
+        if constexpr (TERMS == 3) wm[m] = nm[m];
+      }
     }
   }
 }
 
 // y[M] += W . x in split mode; same contract as lin_T (x, y are fp32 T-tiles).
-template <int KT, int MT>
+template <int KT, int MT, int TERMS = 3>
 __device__ __forceinline__ void lin_S(const float* Wf, const f4* x, f4* y, int lane) {
   constexpr int KP = (KT + 1) / 2;
   XS xs[KP];
 #pragma unroll
   for (int P = 0; P < KP; ++P) xs[P] = split8(x[2 * P], 2 * P + 1 < KT ? x[2 * P + 1] : f4_zero());
-  lin_Sx<KT, MT>(Wf, xs, y, lane);
+  lin_Sx<KT, MT, true, TERMS>(Wf, xs, y, lane);
 }
 
-template <bool SP, int KT, int MT>
+// Arithmetic mode as a template argument of the kernels: SP = GPN_PREC_FP32 (0), GPN_PREC_BF16X3 (1) or
+// GPN_PREC_BF16 (2).  Both bf16 modes share the operand formats and LDS images ("split" layout: hi and mid
+// pieces side by side); the plain mode issues only the hi * hi MFMA of every product.
+constexpr int bf_terms(int sp) { return sp == 2 ? 1 : 3; }
+template <int SP, int KT, int MT>
 __device__ __forceinline__ void lin(const float* W, int ldw, const f4* x, f4* y, int lane) {
-  if constexpr (SP) lin_S<KT, MT>(W, x, y, lane);
+  if constexpr (SP != 0) lin_S<KT, MT, bf_terms(SP)>(W, x, y, lane);
   else lin_T<KT, MT>(W, ldw, x, y, lane);
 }
 
@@ -514,10 +533,10 @@ __device__ __forceinline__ void stage_split(float* dstf, const float* __restrict
 }
 
 // Weight staging in either mode: [rows, cols] -> image of [prow, 16*kt] (fp32: leading dimension ldw).
-template <bool SP>
+template <int SP>
 __device__ __forceinline__ void stage_w(float* dst, int ldw, const float* __restrict__ src, int rows,
                                         int cols, int prow, int kt, int tid, int nthreads) {
-  if constexpr (SP) {
+  if constexpr (SP != 0) {
     stage_split(dst, src, rows, cols, prow, kt, tid, nthreads);
   } else {
     if (rows == prow && cols == 16 * kt && (cols & 3) == 0) stage_matrix(dst, ldw, src, rows, cols, tid, nthreads);
@@ -663,7 +682,7 @@ struct SplitStage {  // bf16x3 fragment-major image (stage_split)
   }
 };
 
-template <bool SP, int PROW, int KT, int NTHR>
+template <bool SPLIT, int PROW, int KT, int NTHR>
 struct WStageSel {
   typedef RowStage<PROW, 4 * KT, NTHR> type;
 };
@@ -671,9 +690,9 @@ template <int PROW, int KT, int NTHR>
 struct WStageSel<true, PROW, KT, NTHR> {
   typedef SplitStage<PROW, KT, NTHR> type;
 };
-// image of a [rows, cols] matrix zero-padded to [PROW, 16*KT] in either mode (stage_w)
-template <bool SP, int PROW, int KT, int NTHR>
-using WStage = typename WStageSel<SP, PROW, KT, NTHR>::type;
+// image of a [rows, cols] matrix zero-padded to [PROW, 16*KT] in any mode (stage_w); SP = GPN_PREC_*
+template <int SP, int PROW, int KT, int NTHR>
+using WStage = typename WStageSel<(SP != 0), PROW, KT, NTHR>::type;
 
 template <int PADDED, int NTHR>
 struct VecStage {  // stage_vector

@@ -15,7 +15,8 @@
  *   - N = R*S points in ray-major order (point n = r*S + s), V source views; N and N*V must fit a
  *     32-bit int (checked: GPN_E_ARG otherwise);
  *   - stateless and re-entrant: no entry point reads or writes process-global state (ABI 2: the
- *     arithmetic mode is an argument / a field of gpn_gnt_weights_t, not a global switch).  Calls
+ *     arithmetic mode is an argument / a field of gpn_gnt_weights_t, not a global switch; ABI 3 adds
+ *     GPN_PREC_BF16).  Calls
  *     that share an output tensor or a workspace must of course be ordered by the caller (same
  *     stream, or events).  The measurement hooks at the end of this header are the one exception:
  *     one timing session per process at a time (serialised by a mutex).
@@ -30,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GPN_ABI_VERSION 2
+#define GPN_ABI_VERSION 3
 #define GPN_OK 0
 #define GPN_E_ARG (-1)     /* invalid argument (shape / null pointer / unsupported size) */
 #define GPN_E_LAUNCH (-2)  /* HIP reported an error at launch */
@@ -54,9 +55,17 @@ typedef void* gpn_stream_t;
  *   GPN_PREC_BF16X3 every fp32 operand is split into two bf16 pieces (hi + mid) and a product is
  *                   w_mid*x_hi + w_hi*x_mid + w_hi*x_hi on v_mfma_f32_16x16x32_bf16 with fp32
  *                   accumulation: ~2^-16 relative error per product, 5.3x the MFMA rate.
- *                   Softmax, LayerNorm, residuals, the projector and the semantic pass stay fp32. */
+ *                   Softmax, LayerNorm, residuals, the projector and the semantic pass stay fp32.
+ *   GPN_PREC_BF16   plain bf16 operands (round to nearest even), ONE v_mfma_f32_16x16x32_bf16 per product,
+ *                   fp32 accumulation; softmax, LayerNorm, residuals, biases, the projector and the semantic
+ *                   pass stay fp32 (BASELINE.json configs[4]: "bf16 attention").  Operand formats and weight
+ *                   images are those of GPN_PREC_BF16X3 (the residual pieces are simply not multiplied), so
+ *                   `feat` tensors of the two modes are interchangeable.  ~2^-9 relative error per product:
+ *                   NOT within the 1e-4 bar of the other two modes -- measured tolerances in DESIGN.md
+ *                   section 3.1 and tests/test_gpu_parity.py (BF16_TOL). */
 #define GPN_PREC_FP32 0
 #define GPN_PREC_BF16X3 1
+#define GPN_PREC_BF16 2
 
 int gpn_abi_version(void);
 const char* gpn_last_error(void); /* thread-local, valid until the next failing call */

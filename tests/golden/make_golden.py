@@ -131,8 +131,11 @@ def g8():
                        t + "_margin": np_(top2[0] - top2[1]),
                        t + "_logits_sub": np_(logits[0, :, ::4, ::4]),
                        t + "_logits_absmax": np.float64(logits.abs().max().item())})
+    # sha: every input incl. the rays (torch CPU inverse / bmm: may differ in the last bit on another CPU);
+    # sha_maps: the hash-generated inputs only (bit-identical anywhere) -- what the GPU box checks
     save("g8_scannet_labels", sha=cases.sha(dict(rb=rb, f=c["featmaps"], d=c["deep_semantics"], h=c["head"])),
-         **arrays)
+         sha_maps=cases.sha(dict(f=c["featmaps"], d=c["deep_semantics"], h=c["head"], s=rb["src_rgbs"],
+                                 c=rb["src_cameras"])), **arrays)
 
 
 @torch.no_grad()

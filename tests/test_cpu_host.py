@@ -25,7 +25,7 @@ def test_cabi_exports_every_declared_symbol():
     missing = [n for n in sorted(declared) if not hasattr(h, n)]
     assert not missing, "declared in include/gpnerf_hip.h but not exported: %s" % missing
     assert set(_lib.EXPORTS) == declared, "ctypes bindings out of sync with the header"
-    assert _lib.lib().gpn_abi_version() == 2
+    assert _lib.lib().gpn_abi_version() == 3
 
 
 def test_ctypes_struct_layout_matches_header_sizes():

@@ -844,6 +844,76 @@ def test_two_streams_have_their_own_workspace(dev, net):
     net.precision = "fp32"
 
 
+# ------------------------------------------------------------------------------ plain bf16 mode (configs[4])
+# GPN_PREC_BF16: one bf16 MFMA per product, fp32 accumulation (include/gpnerf_hip.h).  north_star: "within 1e-4
+# relative (fp32) or a stated bf16 tolerance" -- stated here, from measurement on the golden vectors (DESIGN.md
+# section 3.1): relative to the tensor scale, like TOL.
+# Measured (round 3): rgb 5.2e-3 .. 6.9e-3, depth 1.1e-4 .. 3.5e-4, semantic features 1.5e-4 .. 4.6e-4, attention
+# weights 2e-5 .. 4e-5; label agreement with the reference chain 76,776 / 76,800 (coarse), 76,358 / 76,800 (fine).
+BF16_TOL = {"forward": 1e-2, "render": 1e-2, "depth_sem": 1e-3, "labels_coarse": 0.999, "labels_fine": 0.99}
+
+
+@pytest.mark.parametrize("S", [48, 64])
+def test_plain_bf16_forward_vs_golden(dev, net, golden, S):
+    """GNT.forward in the plain-bf16 mode against the reference's golden vectors (g2) and against the fp32 mode
+    on the same inputs: within BF16_TOL, attention weights still a distribution, deterministic."""
+    g = golden("g2_gnt_s%d" % S)
+    cd = to(dev, cases.g2_gnt(S))
+    args_ = (cd["rgb_feat"], cd["deep_sem"], cd["ray_diff"], cd["mask"], cd["pts"], cd["ray_d"])
+    net.precision = "bf16"
+    out, sem, sem3d = net(*args_)
+    out_b, sem_b, _ = net(*args_)
+    net.precision = "fp32"
+    out32, sem32, _ = net(*args_)
+    assert torch.equal(out, out_b) and torch.equal(sem, sem_b), "plain-bf16 forward is not deterministic"
+    errs = {"out": rel(out, g["out"]), "sem": rel(sem, g["sem"]), "out_vs_fp32": rel(out, out32),
+            "sem_vs_fp32": rel(sem, sem32)}
+    errs["sem3d"] = rel(sem3d, g["sem3d"]) if S == 48 else rel(sem3d.double().sum(-1), g["sem3d_sum"])
+    print("plain bf16 forward errors [S=%d]: %s" % (S, errs))
+    assert max(errs.values()) < BF16_TOL["forward"], errs
+    assert max(errs["sem"], errs["sem3d"]) < BF16_TOL["depth_sem"], errs
+    assert min(errs["out"], errs["sem"]) > 1e-5, "suspiciously exact: is the bf16 mode running the bf16x3 products?"
+    assert rel(out[:, 3:].sum(-1), np.ones(out.shape[0], np.float32)) < 1e-5  # weights sum to 1 (fp32 softmax)
+
+
+def test_plain_bf16_render_rays_and_stress_shape(dev, net, golden):
+    """render_rays in the plain-bf16 mode: (a) golden g4 (reference's own two-pass render), coarse level within
+    BF16_TOL (the fine level sits behind the inverse-CDF resampling: bounded loosely); (b) BASELINE configs[4]'s
+    shape on a small image (16 views, 96 + 32 samples) against the CPU oracle, coarse level."""
+    from gp_nerf_amd import synth
+    from gp_nerf_amd.projection import Projector
+    from gp_nerf_amd.render_ray import render_rays
+    net.precision = "bf16"
+    try:
+        g = golden("g4_render_rays")
+        c = cases.g4_render_rays()
+        ret = render_rays(to(dev, c["ray_batch"]), _model(net), c["featmaps"].to(dev), c["deep_semantics"].to(dev),
+                          Projector(dev), N_samples=48, inv_uniform=True, N_importance=16, det=True,
+                          ret_alpha=True, single_net=True)
+        errs = {k: rel(ret["outputs_coarse"][k], g["coarse_" + k]) for k in ("rgb", "weights", "depth", "feats_out")}
+        errs["fine_rgb"] = rel(ret["outputs_fine"]["rgb"], g["fine_rgb"])
+        K = synth.scaled_intrinsics(synth.SCANNET_K, 0.3, 0.3)
+        sc = synth.Scene(72, 96, 16, K, (0.1, 6.0), seed=99, rig=dict(dx=0.06, dy=0.02, yaw_deg=-1.5))
+        sel = (torch.arange(37) * 173) % sc.rays_o.shape[0]
+        rb = sc.ray_batch()
+        rb["ray_o"], rb["ray_d"] = sc.rays_o[sel].contiguous(), sc.rays_d[sel].contiguous()
+        want = oracle.render.render_rays(rb, cases.weights(), sc.featmaps, sc.deep_semantics, N_samples=96,
+                                         inv_uniform=True, N_importance=0, det=True, ret_alpha=True)
+        got = render_rays(to(dev, rb), _model(net), sc.featmaps.to(dev), sc.deep_semantics.to(dev), Projector(dev),
+                          N_samples=96, inv_uniform=True, N_importance=32, det=True, ret_alpha=True, single_net=True)
+        for k in ("rgb", "weights", "depth", "feats_out"):
+            errs["stress_" + k] = rel(got["outputs_coarse"][k], want["outputs_coarse"][k])
+        assert got["outputs_fine"]["weights"].shape[1] == 128
+        assert bool(torch.isfinite(got["outputs_fine"]["feats_out"]).all())
+    finally:
+        net.precision = "fp32"
+    print("plain bf16 render_rays errors: %s" % errs)
+    fine = errs.pop("fine_rgb")
+    assert max(errs.values()) < BF16_TOL["render"], errs
+    assert max(v for k, v in errs.items() if not k.endswith("rgb")) < BF16_TOL["depth_sem"], errs
+    assert fine < 0.2, fine
+
+
 # ------------------------------------------------------------------------------ render_rays / image
 def _model(net):
     return types.SimpleNamespace(net_coarse=net, net_fine=None)
@@ -1265,7 +1335,7 @@ def test_scannet_eval_view_full_size(dev):
     assert float(clear.float().mean()) > 0.9
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3", "bf16"])
 def test_scannet_labels_vs_reference_chain(dev, net, mode, golden):
     """BASELINE.json configs[2] at full size against THE REFERENCE's renderer: golden g8 holds, for the 19,200
     rays of the half-resolution grid of a 240x320 ScanNet-shaped view (10 views, 48 + 16 samples), the
@@ -1279,8 +1349,9 @@ def test_scannet_labels_vs_reference_chain(dev, net, mode, golden):
     from gp_nerf_amd.semantic_branch import NeRFSemSegFPNHead, semantic_labels
     g = golden("g8_scannet_labels")
     c = cases.g8_scannet_labels()
-    assert np.array_equal(cases.sha(dict(rb=c["ray_batch"], f=c["featmaps"], d=c["deep_semantics"], h=c["head"])),
-                          g["sha"])
+    # (the hash-generated inputs; the rays come from torch's CPU inverse / bmm, whose last bit is the host's)
+    assert np.array_equal(cases.sha(dict(f=c["featmaps"], d=c["deep_semantics"], h=c["head"],
+                                         s=c["ray_batch"]["src_rgbs"], c=c["ray_batch"]["src_cameras"])), g["sha_maps"])
     net.precision = mode
     rb = to(dev, c["ray_batch"])
     fm, deep = c["featmaps"].to(dev), c["deep_semantics"].to(dev)
@@ -1316,6 +1387,11 @@ def test_scannet_labels_vs_reference_chain(dev, net, mode, golden):
                          wrong_where_clear=int((~agree & clear).sum()))
     print("scannet labels vs the reference chain [%s]: %s" % (mode, report))
     net.precision = "fp32"
+    if mode == "bf16":  # the stated bf16 tolerance and label-agreement rate (no margin-conditional claim)
+        assert max(report["coarse"]["errs"].values()) < BF16_TOL["render"], report["coarse"]
+        assert report["coarse"]["agree"] >= BF16_TOL["labels_coarse"] * report["coarse"]["pixels"], report["coarse"]
+        assert report["fine"]["agree"] >= BF16_TOL["labels_fine"] * report["fine"]["pixels"], report["fine"]
+        return
     # coarse level: continuous in the arithmetic -> the full bar; fine level: rays whose importance samples
     # cross a knife edge differ by O(1) in feats_out on any two platforms, so its
     # tensors are bounded loosely and its labels only counted

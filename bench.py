@@ -191,9 +191,11 @@ def ray_chunk(scene, rank, world, dev):
     start = ((r0 + r1) // 2) * scene.W
     start = min(start, scene.H * scene.W - CHUNK)
     sl = slice(start, start + CHUNK)
+    # pixel_row: the chunk is consecutive pixels of the image (render_single_image sets the same hint per chunk)
     return {"ray_o": scene.rays_o[sl].to(dev), "ray_d": scene.rays_d[sl].to(dev),
             "depth_range": scene.depth_range, "camera": scene.camera,
-            "src_rgbs": scene.src_rgbs, "src_cameras": scene.src_cameras}
+            "src_rgbs": scene.src_rgbs, "src_cameras": scene.src_cameras,
+            "pixel_row": (scene.W, start % scene.W)}
 
 
 def visibility_stats(scene, rb, projector, n_samples, n_importance, coarse_weights=None):
@@ -225,7 +227,7 @@ def cpu_baseline(scene, rb, n_rays):
     threads = min(16, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     sd = synth.gnt_state_dict()
-    rbc = {k: v.cpu() for k, v in rb.items()}
+    rbc = {k: v.cpu() for k, v in rb.items() if isinstance(v, torch.Tensor)}
     rbc["ray_o"], rbc["ray_d"] = rbc["ray_o"][:n_rays], rbc["ray_d"][:n_rays]
     feat, deep = scene.featmaps.cpu(), scene.deep.cpu()
     t0 = time.perf_counter()
@@ -888,7 +890,7 @@ def compare_with_cpu(scene, rb, projector, ret, want, nr, dev):
     of the fine-level comparison."""
     import oracle
     from gp_nerf_amd import render_ray as rr
-    rbc = {k: v.cpu() for k, v in rb.items()}
+    rbc = {k: v.cpu() for k, v in rb.items() if isinstance(v, torch.Tensor)}
     rbc["ray_o"], rbc["ray_d"] = rbc["ray_o"][:nr], rbc["ray_d"][:nr]
     _, zc = oracle.sampling.sample_along_camera_ray(rbc["ray_o"], rbc["ray_d"], rbc["depth_range"],
                                                     N_SAMPLES, inv_uniform=True, det=True)

@@ -78,7 +78,8 @@ class SemArgs(C.Structure):
                 ("xyz", C.c_void_p), ("proj", C.c_void_p),
                 ("img_h", C.c_float), ("img_w", C.c_float),
                 ("sem3d", C.c_void_p), ("pre", C.c_void_p),
-                ("attn2_w", C.c_void_p * MAX_DEPTH), ("attn2_b", C.c_void_p * MAX_DEPTH)]
+                ("attn2_w", C.c_void_p * MAX_DEPTH), ("attn2_b", C.c_void_p * MAX_DEPTH),
+                ("ray_row_width", C.c_int), ("ray_row_offset", C.c_int)]
 
 
 _P = C.c_void_p

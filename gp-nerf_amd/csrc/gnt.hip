@@ -2452,6 +2452,12 @@ k_ray1(gpn_ray_layer_t Lw, const float* x_in, int R, int S, float* x_out,
 #if SEM_PREFETCH
 #error "SEM_PREFETCH=1 is stale: the prefetch pipeline predates `live = vis ? vis : (all_views & tab.hit)` and would blend the wrong taps"
 #endif
+#ifndef SEM_HS
+#define SEM_HS 0  // 1: the 8 x DEPTH hidden values of a (sample, view) pair come in through SCALAR loads (the pair is
+                  // wave-uniform: one wave = one ray) and enter the packed fmas as SGPR operands -- no LDS round
+                  // trip for them (the LDS pipe was the kernel's busiest unit: 32 ds_read_b128 per pair, half
+                  // of them broadcast reads of these values); 0: vector load -> LDS slot -> broadcast reads
+#endif
 typedef const __attribute__((address_space(4))) float* sem_cfp;
 __device__ __forceinline__ float rl_f(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
@@ -2462,7 +2468,7 @@ __device__ __forceinline__ unsigned rl_u(unsigned v, int l) {
 
 template <int DEPTH>
 __global__ void __launch_bounds__(SEM_RAYS * 64, SEM_WAVES_PER_SIMD)
-k_sem(gpn_sem_args_t a) {
+k_sem(gpn_sem_args_t a, int strip_groups) {
   constexpr int LP = (DEPTH + 1) / 2;  // layers are processed in pairs (v_pk_fma_f32)
   __shared__ float sP[GPN_MAX_VIEWS * 12];
   __shared__ __attribute__((aligned(16))) float sH[SEM_RAYS][LP * 16];
@@ -2473,7 +2479,35 @@ k_sem(gpn_sem_args_t a) {
   // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2): give each XCD a
   // contiguous run of ray groups.
   int blk = blockIdx.x;
-  {
+  if (strip_groups > 0) {
+    // Rays are consecutive pixels in row-major order, G = 8 x strip_groups groups of SEM_RAYS rays per image
+    // row, the chunk starting g0 groups into its first row (gpn_sem_args_t.ray_row_*).  The groups are put in
+    // the order (column strip, row, column inside the strip) and that sequence is cut into 8 equal runs, one
+    // per XCD (workgroups b and b + 8 share an XCD): an XCD works on a 2-D patch of the image -- the rows of a
+    // strip share texel rows -- instead of a 1-D run of rays, with the same number of workgroups as before.
+    const int groups = (a.R + SEM_RAYS - 1) / SEM_RAYS, G = strip_groups * 8;
+    const int g0 = a.ray_row_offset / SEM_RAYS, g1 = g0 + groups;  // the chunk in "virtual" group numbers
+    const int nb = gridDim.x, per = nb >> 3;
+    int p = blk < per * 8 ? (blk & 7) * per + (blk >> 3) : blk;  // position in the sequence
+    // virtual groups below n that lie in strip k: whole rows + the part of the last row
+    auto below = [&](int n, int k) { return (n / G) * strip_groups + min(max(n % G - k * strip_groups, 0), strip_groups); };
+    int k = 0;
+    for (; k < 7; ++k) {
+      const int nk = below(g1, k) - below(g0, k);
+      if (p < nk) break;
+      p -= nk;
+    }
+    // the p-th group of strip k: its first row may start inside the strip (or past it)
+    const int row0 = g0 / G, first = strip_groups - min(max(g0 % G - k * strip_groups, 0), strip_groups);
+    int row, col;
+    if (p < first) {
+      row = row0, col = (k + 1) * strip_groups - first + p;
+    } else {
+      p -= first;
+      row = row0 + 1 + p / strip_groups, col = k * strip_groups + p % strip_groups;
+    }
+    blk = row * G + col - g0;
+  } else {
     const int nb = gridDim.x, per = nb >> 3;
     if (per > 0 && blk < per * 8) blk = (blk & 7) * per + (blk >> 3);
   }
@@ -2512,11 +2546,19 @@ k_sem(gpn_sem_args_t a) {
       b = a.attn2_b[l] ? a.attn2_b[l][lane] : 0.0f;
     }
     if (wave == 0) {  // one wave fills the image (every wave would write the same values)
+#if SEM_HS
+      // one 16-byte unit per lane, layer and half of the hidden values: (w[l][4h], .., w[l][4h+3])
+      if (l < DEPTH) {
+        st4(sW + ((l * 2 + 0) * 64 + lane) * 4, w0 * f4_splat(LOG2E_F));
+        st4(sW + ((l * 2 + 1) * 64 + lane) * 4, w1 * f4_splat(LOG2E_F));
+      }
+#else
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         sW[(((l >> 1) * 4 + (k >> 1)) * 64 + lane) * 4 + (k & 1) * 2 + (l & 1)] = w0[k] * LOG2E_F;
         sW[(((l >> 1) * 4 + 2 + (k >> 1)) * 64 + lane) * 4 + (k & 1) * 2 + (l & 1)] = w1[k] * LOG2E_F;
       }
+#endif
     }
     a2b[l >> 1][l & 1] = b;
   }
@@ -2606,9 +2648,11 @@ k_sem(gpn_sem_args_t a) {
     // hidden layer of attn_fc for all DEPTH layers of a (sample, view): 8*DEPTH floats, one per lane,
     // fetched one view ahead; every lane needs all of them, so they go through an LDS slot of the
     // wave and come back as broadcast reads (same address in all lanes: conflict free)
-    float hvn = 0.f;
+    [[maybe_unused]] float hvn = 0.f;
+#if !SEM_HS
     if (vis != 0 && lane < DEPTH * 8)
       hvn = __builtin_nontemporal_load(a.hidden + (n * V + __builtin_ctz(live)) * (DEPTH * 8) + lane);
+#endif
     // bias - log-sum-exp, in log2 units: the constant part of every logit of this sample
 #pragma unroll
     for (int p = 0; p < LP; ++p) bl[p] = (a2b[p] - bl[p]) * (f2){LOG2E_F, LOG2E_F};
@@ -2619,11 +2663,13 @@ k_sem(gpn_sem_args_t a) {
     while (live) {
       const int v = __builtin_ctz(live);
       live &= live - 1;
+#if !SEM_HS
       if (vis != 0) {
         if (lane < DEPTH * 8) sH[wave][hslot] = hvn;
         if (live && lane < DEPTH * 8)
           hvn = __builtin_nontemporal_load(a.hidden + (n * V + __builtin_ctz(live)) * (DEPTH * 8) + lane);
       }
+#endif
       f4 d0, d1;
       if (dense) {
         const float* dd = a.deep_dense + (n * V + v) * GPN_SEM;
@@ -2645,6 +2691,37 @@ k_sem(gpn_sem_args_t a) {
         }
       }
       float w3 = w3u, w2 = w2u;
+#if SEM_HS
+      if (vis != 0) {
+        // logits of this lane's channel group in all layers: attn_fc[2] row . hidden + bias (:66-70); the
+        // hidden values are wave-uniform -> scalar loads, SGPR-pair operands of the packed fmas (even and
+        // odd hidden values of ONE layer in the two halves, summed before the exponential);
+        // softmax weight = 2^(logit - lse) in log2 units
+        // (the element offset is wave-uniform by construction; readfirstlane tells the compiler so, which is what
+        // turns these loads into s_load_dwordx2 and the operands into SGPR pairs)
+        const unsigned long long ho = (unsigned long long)((n * V + v) * (DEPTH * 8));
+        const unsigned long long hou =
+            (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ho) |
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ho >> 32)) << 32);
+        sem_cfp hs = (sem_cfp)a.hidden + hou;
+        w3 = 0.f, w2 = 0.f;
+#pragma unroll
+        for (int l = 0; l < DEPTH; ++l) {
+          f2 lg = (f2){bl[l >> 1][l & 1], 0.f};
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const f4 w = ld4(sW + ((l * 2 + hh) * 64 + lane) * 4);
+            const f2 h0 = (f2){hs[8 * l + 4 * hh + 0], hs[8 * l + 4 * hh + 1]};
+            const f2 h1 = (f2){hs[8 * l + 4 * hh + 2], hs[8 * l + 4 * hh + 3]};
+            lg = w.lo * h0 + lg;
+            lg = w.hi * h1 + lg;
+          }
+          const float at = __builtin_amdgcn_exp2f(lg.x + lg.y);
+          w3 += at;
+          w2 = ab[l >> 1][l & 1] * at + w2;
+        }
+      }
+#else
       if (vis != 0) {
         // logits of this lane's channel group in all layers: attn_fc[2] row . hidden + bias (:66-70),
         // two layers per packed fma; softmax weight = 2^(logit - lse) in log2 units
@@ -2668,6 +2745,7 @@ k_sem(gpn_sem_args_t a) {
         }
         w3 = w3p.x + w3p.y, w2 = w2p.x + w2p.y;
       }
+#endif
       // weights of the two channel groups this lane's channels belong to
       const float w3A = __shfl(w3, lane >> 1), w3B = __shfl(w3, 32 + (lane >> 1));
       const float w2A = __shfl(w2, lane >> 1), w2B = __shfl(w2, 32 + (lane >> 1));
@@ -3231,17 +3309,25 @@ extern "C" int gpn_sem_aggregate(const gpn_sem_args_t* a, gpn_stream_t stream) {
   if (a->R == 0) return GPN_OK;
   GpnStageTimer timer_k_sem_(GPN_ST_SEM, (hipStream_t)stream);
   const int groups = gpn_ceil_div(a->R, SEM_RAYS);
-  const dim3 grid(groups), block(SEM_RAYS * 64);
+  // 2-D strips per XCD (gpn_sem_args_t.ray_row_*): whole groups per strip, whole workgroups per XCD, the chunk
+  // at least two rows tall (GPN_SEM_NO_STRIPS=1: developer switch for A/B measurements)
+  int strip_groups = 0;
+  const int ngrid = groups;
+  if (a->ray_row_width >= 8 * SEM_RAYS && a->ray_row_width % (8 * SEM_RAYS) == 0 && a->ray_row_offset >= 0 &&
+      a->ray_row_offset < a->ray_row_width && a->ray_row_offset % SEM_RAYS == 0 &&
+      a->R >= 2 * a->ray_row_width && a->deep_map != nullptr && !getenv("GPN_SEM_NO_STRIPS"))
+    strip_groups = a->ray_row_width / (8 * SEM_RAYS);
+  const dim3 grid(ngrid), block(SEM_RAYS * 64);
   hipStream_t st = (hipStream_t)stream;
   switch (a->depth) {
-    case 1: hipLaunchKernelGGL(k_sem<1>, grid, block, 0, st, *a); break;
-    case 2: hipLaunchKernelGGL(k_sem<2>, grid, block, 0, st, *a); break;
-    case 3: hipLaunchKernelGGL(k_sem<3>, grid, block, 0, st, *a); break;
-    case 4: hipLaunchKernelGGL(k_sem<4>, grid, block, 0, st, *a); break;
-    case 5: hipLaunchKernelGGL(k_sem<5>, grid, block, 0, st, *a); break;
-    case 6: hipLaunchKernelGGL(k_sem<6>, grid, block, 0, st, *a); break;
-    case 7: hipLaunchKernelGGL(k_sem<7>, grid, block, 0, st, *a); break;
-    default: hipLaunchKernelGGL(k_sem<8>, grid, block, 0, st, *a); break;
+    case 1: hipLaunchKernelGGL(k_sem<1>, grid, block, 0, st, *a, strip_groups); break;
+    case 2: hipLaunchKernelGGL(k_sem<2>, grid, block, 0, st, *a, strip_groups); break;
+    case 3: hipLaunchKernelGGL(k_sem<3>, grid, block, 0, st, *a, strip_groups); break;
+    case 4: hipLaunchKernelGGL(k_sem<4>, grid, block, 0, st, *a, strip_groups); break;
+    case 5: hipLaunchKernelGGL(k_sem<5>, grid, block, 0, st, *a, strip_groups); break;
+    case 6: hipLaunchKernelGGL(k_sem<6>, grid, block, 0, st, *a, strip_groups); break;
+    case 7: hipLaunchKernelGGL(k_sem<7>, grid, block, 0, st, *a, strip_groups); break;
+    default: hipLaunchKernelGGL(k_sem<8>, grid, block, 0, st, *a, strip_groups); break;
   }
   GPN_LAUNCH_CHECK("k_sem");
   return GPN_OK;

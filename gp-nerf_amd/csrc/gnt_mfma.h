@@ -66,7 +66,9 @@ __device__ __forceinline__ void st4_nt(float* p, f4 v) { __builtin_nontemporal_s
 // write-through store (sc0 sc1: the line does not stay dirty in this XCD's L2, so the release at the
 // end of the kernel has nothing of it left to write back)
 __device__ __forceinline__ void st4_wt(float* p, f4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  // (s_nop: the store-data hazard -- a VALU write of `v`'s registers right behind a > 64-bit store -- is padded
+  // by the compiler for its own stores only)
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 #if defined(GPN_FF_ST) && GPN_FF_ST == 1
 #define FF_ST st4_nt

@@ -6,6 +6,7 @@
 // outputs are written once, fully coalesced.  Built with -ffp-contract=off.
 #include "common.h"
 #include "proj_common.h"
+#include <climits>
 
 // ---------------------------------------------------------------- NCHW -> NHWC repack
 __global__ void k_repack_nhwc(const float* __restrict__ src, float* __restrict__ dst, int C,
@@ -177,56 +178,161 @@ k_project_feat(gpn_project_args_t a, long long n_pairs) {
 // fully coalesced 1 KiB wave loads, the output row two 1 KiB wave stores (non-temporal: 5.4 GB at the
 // north-star shape, written once -- they must not evict the texels the next pairs re-read).
 // Order of the pairs.  The four taps of a pair are 8 KB of map; neighbouring RAYS at the same sample
-// index and view project half a texel apart and share most of them, while consecutive samples or
-// views share nothing.  With the samples-per-ray hint a wave therefore walks PD_RUN consecutive rays
-// of one (sample, view), and the four waves of a workgroup the next runs of the same (sample, view):
-// measured HBM fetch per call 6.9 GB (pair-major order, r02a) against 0.8 GB of maps.
+// index and view project half a texel apart and share most of them, and the samples of the rays of one image
+// row run along (nearly) one epipolar line of a source view: everything a block of a few hundred consecutive rays
+// reads from ONE view over ALL its samples is two or three texel rows (~2 MB), while the chunk as a whole
+// touches each texel about ten times, spread over far-apart (sample, view) slabs.  Every XCD has its own 4 MB
+// L2 and workgroups are dealt to the XCDs round-robin (blockIdx % 8), so with the samples-per-ray hint the
+// work is cut into UNITS = (block of PD_RB rays, view); XCD x walks a contiguous run of units (ray blocks of
+// one view back to back: consecutive image rows share texel rows), all of its workgroups together inside
+// one unit, sample-major with the rays innermost (the waves of a workgroup take consecutive rays of one
+// sample at the same time: shared taps meet in the L1).  A unit's texels are then fetched from HBM once.
+// Measured HBM fetch per call at the north-star shape (0.16 GB of distinct texels, 1.57 GB of maps): pair-major
+// order 6.9 GB (r02a), slabs of one (sample, view) across the chip 3.1 GB (r02), units per XCD: profiles/r03_*.
+// Without the hint (S = 1), or with fewer units than XCDs, the old slab order is used.
 #define PD_RUN 16
+#ifndef PD_RB
+#define PD_RB 256  // rays per unit (with PD_URUN 8: 2 items per wave and unit at 32 waves per CU)
+#endif
+#ifndef PD_STORE
+#define PD_STORE 0  // 0: nontemporal; 1: sc1, 2: sc0 sc1 (both measured 1.93 vs 1.40 ms: write-through in 16-byte pieces)
+#endif
+#ifndef PD_VIEW_MAJOR
+#define PD_VIEW_MAJOR 0
+#endif
+#ifndef PD_URUN
+#define PD_URUN 8  // consecutive rays a wave takes per item inside a unit (sliding texel window in registers)
+#endif
 __global__ void __launch_bounds__(256)
-k_project_deep(gpn_project_args_t a, long long n_pairs) {
+k_project_deep(gpn_project_args_t a, long long n_pairs, int by_units) {
   __shared__ float sP[GPN_MAX_VIEWS * 12];
   const int tid = threadIdx.x;
   for (int i = tid; i < a.V * 12; i += 256) sP[i] = a.proj[(i / 12) * 16 + (i % 12)];
   __syncthreads();
   const int lane = tid & 63;
-  const long long wave = (long long)blockIdx.x * 4 + (tid >> 6);
-  const long long nwaves = (long long)gridDim.x * 4;
   const int D = a.deep_c;  // 512
   const size_t rs = (size_t)a.deep_w * D;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const int S = a.samples_per_ray > 0 && a.N % a.samples_per_ray == 0 ? a.samples_per_ray : 1;
   const long long R = a.N / S;                      // rays (S == 1: every point is its own "ray")
+  // one (point, view) pair: project, four taps x 2 KB, blend, one 2 KB row out
+  auto do_pair = [&](long long n, int v) {
+    const float* dm = a.deep + (size_t)v * a.deep_h * rs;
+    const long long pair = n * a.V + v;
+    const GpnPix pp = gpn_project(sP + v * 12, a.xyz[n * 3 + 0], a.xyz[n * 3 + 1], a.xyz[n * 3 + 2]);
+    const GpnTaps t = gpn_taps(pp.px, pp.py, a.img_h, a.img_w, a.deep_h, a.deep_w);
+    const size_t o00 = (size_t)t.y0 * rs + (size_t)t.x0 * D;
+    float* out = a.deep_out + pair * D;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int c = half * 256 + lane * 4;
+      float4 vnw = zero4, vne = zero4, vsw = zero4, vse = zero4;
+      if (t.vy0 && t.vx0) vnw = *reinterpret_cast<const float4*>(dm + o00 + c);
+      if (t.vy0 && t.vx1) vne = *reinterpret_cast<const float4*>(dm + o00 + D + c);
+      if (t.vy1 && t.vx0) vsw = *reinterpret_cast<const float4*>(dm + o00 + rs + c);
+      if (t.vy1 && t.vx1) vse = *reinterpret_cast<const float4*>(dm + o00 + rs + D + c);
+      typedef float vf4 __attribute__((ext_vector_type(4)));
+      vf4 o;
+      o.x = gpn_bilerp(vnw.x, vne.x, vsw.x, vse.x, t);
+      o.y = gpn_bilerp(vnw.y, vne.y, vsw.y, vse.y, t);
+      o.z = gpn_bilerp(vnw.z, vne.z, vsw.z, vse.z, t);
+      o.w = gpn_bilerp(vnw.w, vne.w, vsw.w, vse.w, t);
+      // the 2 KB output row is written once and never read here: an `sc1` store leaves the XCD's L2 without
+      // keeping its line there (plain and `nt` stores keep it, MI355X_MICROARCH.md: the 5.4 GB output stream
+      // then evicts the texels the next pairs re-read)
+#if PD_STORE == 1
+      // (s_nop: a VALU write of the data registers right behind a > 64-bit store is a hazard the compiler
+      // pads for its own stores only -- without it 0.6 % of the values came out wrong)
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(out + c), "v"(o) : "memory");
+#elif PD_STORE == 2
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(out + c), "v"(o) : "memory");
+#else
+      __builtin_nontemporal_store(o, reinterpret_cast<vf4*>(out + c));
+#endif
+    }
+  };
+  if (by_units) {  // (gridDim.x is a multiple of 8 here)
+    const int xcd = blockIdx.x & 7;
+    const long long wx = (long long)(blockIdx.x >> 3) * 4 + (tid >> 6), nwx = (long long)(gridDim.x >> 3) * 4;
+    const long long nrb = (R + PD_RB - 1) / PD_RB, U = nrb * a.V;
+    typedef float vf4 __attribute__((ext_vector_type(4)));
+    for (long long u = xcd * U / 8; u < (xcd + 1) * U / 8; ++u) {
+#if PD_VIEW_MAJOR
+      const int v = (int)(u / nrb);
+      const long long r0 = (u - (long long)v * nrb) * PD_RB;
+#else
+      // ray-block major: an XCD walks the views of ONE ray block (the views differ in how many of their pairs
+      // are inside the map, i.e. in cost: view-major runs left the XCDs unbalanced, 1.90 vs 1.54 ms)
+      const long long rbk = u / a.V;
+      const int v = (int)(u - rbk * a.V);
+      const long long r0 = rbk * PD_RB;
+#endif
+      const long long nr = R - r0 < PD_RB ? R - r0 : PD_RB;
+      const long long runs = (nr + PD_URUN - 1) / PD_URUN;
+      const float* dm = a.deep + (size_t)v * a.deep_h * rs;
+      for (long long it = wx; it < runs * S; it += nwx) {
+        const long long s = it / runs, run = it - s * runs;
+        const long long re = (run + 1) * PD_URUN < nr ? (run + 1) * PD_URUN : nr;
+        // A wave walks PD_URUN consecutive rays of one (sample, view) and keeps the 2 x 2 texels of the last
+        // pair in registers (two 16-byte pieces per lane and texel; a texel outside the map is kept as zeros,
+        // grid_sample's padding).  Neighbouring pixels project half a texel apart: the window of the next ray
+        // is the same one (nothing to load) or one column further (two texels to load instead of four) --
+        // same values in the same blend, bit for bit, with a third of the tap requests.
+        int cx = INT_MIN, cy = INT_MIN;  // north-west corner of the cached window (wave-uniform)
+        vf4 c00[2], c01[2], c10[2], c11[2];
+        auto texel = [&](int x, int y, vf4 (&d)[2]) {
+          if (x >= 0 && x < a.deep_w && y >= 0 && y < a.deep_h) {
+            const float* p = dm + (size_t)y * rs + (size_t)x * D + lane * 4;
+            d[0] = *reinterpret_cast<const vf4*>(p);
+            d[1] = *reinterpret_cast<const vf4*>(p + 256);
+          } else {
+            d[0] = d[1] = (vf4){0.f, 0.f, 0.f, 0.f};
+          }
+        };
+        for (long long r = run * PD_URUN; r < re; ++r) {
+          const long long n = (r0 + r) * S + s;
+          const GpnPix pp = gpn_project(sP + v * 12, a.xyz[n * 3 + 0], a.xyz[n * 3 + 1], a.xyz[n * 3 + 2]);
+          const GpnTaps t = gpn_taps(pp.px, pp.py, a.img_h, a.img_w, a.deep_h, a.deep_w);
+          // (the point is wave-uniform, so are these branches)
+          const int x0 = __builtin_amdgcn_readfirstlane(t.x0), y0 = __builtin_amdgcn_readfirstlane(t.y0);
+          if (y0 == cy && x0 == cx) {
+          } else if (y0 == cy && x0 == cx + 1 && cx != INT_MIN) {
+            c00[0] = c01[0], c00[1] = c01[1], c10[0] = c11[0], c10[1] = c11[1];
+            texel(x0 + 1, y0, c01);
+            texel(x0 + 1, y0 + 1, c11);
+          } else {
+            texel(x0, y0, c00);
+            texel(x0 + 1, y0, c01);
+            texel(x0, y0 + 1, c10);
+            texel(x0 + 1, y0 + 1, c11);
+          }
+          cx = x0, cy = y0;
+          float* out = a.deep_out + (n * a.V + v) * D + lane * 4;
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            vf4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = gpn_bilerp(c00[half][e], c01[half][e], c10[half][e], c11[half][e], t);
+#if PD_STORE == 3
+            *reinterpret_cast<vf4*>(out + half * 256) = o;
+#else
+            __builtin_nontemporal_store(o, reinterpret_cast<vf4*>(out + half * 256));
+#endif
+          }
+        }
+      }
+    }
+    return;
+  }
+  const long long wave = (long long)blockIdx.x * 4 + (tid >> 6);
+  const long long nwaves = (long long)gridDim.x * 4;
   const long long runs = (R + PD_RUN - 1) / PD_RUN;  // runs of rays per (sample, view)
   const long long items = runs * S * a.V;
   for (long long it = wave; it < items; it += nwaves) {
     const long long sv = it / runs, run = it - sv * runs;
     const int s = (int)(sv / a.V), v = (int)(sv - (long long)s * a.V);
-    const float* dm = a.deep + (size_t)v * a.deep_h * rs;
     const long long r_end = (run + 1) * PD_RUN < R ? (run + 1) * PD_RUN : R;
-    for (long long r = run * PD_RUN; r < r_end; ++r) {
-      const long long n = r * S + s;
-      const long long pair = n * a.V + v;
-      const GpnPix pp = gpn_project(sP + v * 12, a.xyz[n * 3 + 0], a.xyz[n * 3 + 1], a.xyz[n * 3 + 2]);
-      const GpnTaps t = gpn_taps(pp.px, pp.py, a.img_h, a.img_w, a.deep_h, a.deep_w);
-      const size_t o00 = (size_t)t.y0 * rs + (size_t)t.x0 * D;
-      float* out = a.deep_out + pair * D;
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int c = half * 256 + lane * 4;
-        float4 vnw = zero4, vne = zero4, vsw = zero4, vse = zero4;
-        if (t.vy0 && t.vx0) vnw = *reinterpret_cast<const float4*>(dm + o00 + c);
-        if (t.vy0 && t.vx1) vne = *reinterpret_cast<const float4*>(dm + o00 + D + c);
-        if (t.vy1 && t.vx0) vsw = *reinterpret_cast<const float4*>(dm + o00 + rs + c);
-        if (t.vy1 && t.vx1) vse = *reinterpret_cast<const float4*>(dm + o00 + rs + D + c);
-        typedef float vf4 __attribute__((ext_vector_type(4)));
-        vf4 o;
-        o.x = gpn_bilerp(vnw.x, vne.x, vsw.x, vse.x, t);
-        o.y = gpn_bilerp(vnw.y, vne.y, vsw.y, vse.y, t);
-        o.z = gpn_bilerp(vnw.z, vne.z, vsw.z, vse.z, t);
-        o.w = gpn_bilerp(vnw.w, vne.w, vsw.w, vse.w, t);
-        __builtin_nontemporal_store(o, reinterpret_cast<vf4*>(out + c));
-      }
-    }
+    for (long long r = run * PD_RUN; r < r_end; ++r) do_pair(r * S + s, v);
   }
 }
 
@@ -277,9 +383,15 @@ extern "C" int gpn_project_gather(const gpn_project_args_t* a, gpn_stream_t stre
   }
   if (want_deep) {
     const long long blocks = (n_pairs / PD_RUN + 4) / 4;
-    const int grid = (int)(blocks < (long long)cus * 8 ? blocks : (long long)cus * 8);
+    int grid = (int)(blocks < (long long)cus * 8 ? blocks : (long long)cus * 8);
+    // (ray block, view) units per XCD: needs the samples-per-ray hint, at least two units per XCD and enough
+    // pairs to fill the chip (the grid is then a multiple of the 8 XCDs)
+    const int S_ = a->samples_per_ray > 0 && a->N % a->samples_per_ray == 0 ? a->samples_per_ray : 1;
+    const long long units = (((long long)a->N / S_ + PD_RB - 1) / PD_RB) * a->V;
+    const int by_units = S_ > 1 && units >= 16 && blocks >= (long long)cus * 8;
+    if (by_units) grid = (cus * 8) & ~7;
     GpnStageTimer timer_k_project_deep_(GPN_ST_PROJECT_DEEP, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_project_deep, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, n_pairs);
+    hipLaunchKernelGGL(k_project_deep, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, n_pairs, by_units);
     GPN_LAUNCH_CHECK("k_project_deep");
   }
   return GPN_OK;

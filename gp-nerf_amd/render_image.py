@@ -19,20 +19,26 @@ _SHARED_KEYS = ("camera", "depth_range", "src_rgbs", "src_cameras", "labels", "s
 
 def _render_chunks(ray_batch, model, projector, chunk_size, N_samples, inv_uniform, N_importance,
                    det, white_bkgd, featmaps, deep_semantics, ret_alpha, single_net, start, stop,
-                   feats_out_3d=True):
+                   feats_out_3d=True, row_width=None):
     """Chunk loop (reference render_image.py:39-85) over rays [start, stop); results stay on the
-    device: {'outputs_coarse': {k: [chunks]}, 'outputs_fine': ... or None}."""
+    device: {'outputs_coarse': {k: [chunks]}, 'outputs_fine': ... or None}.
+    row_width: rays per row when ray_batch holds the whole strided pixel grid in row-major order; every chunk
+    then carries the scheduling hint 'pixel_row' = (row_width, column of its first ray) for render_rays."""
     acc = OrderedDict([("outputs_coarse", OrderedDict()), ("outputs_fine", OrderedDict())])
     for i in range(start, stop, chunk_size):
         j = min(i + chunk_size, stop)
         chunk = OrderedDict()
         for k in ray_batch:
+            if k == "pixel_row":
+                continue
             if k in _SHARED_KEYS:
                 chunk[k] = ray_batch[k]
             elif ray_batch[k] is not None:
                 chunk[k] = ray_batch[k][i:j]
             else:
                 chunk[k] = None
+        if row_width:
+            chunk["pixel_row"] = (row_width, i % row_width)
         ret = render_rays(chunk, model, featmaps, ref_deep_semantics=deep_semantics,
                           projector=projector, N_samples=N_samples, inv_uniform=inv_uniform,
                           N_importance=N_importance, det=det, white_bkgd=white_bkgd,
@@ -121,10 +127,10 @@ def render_single_image(
     tensors: rgb [H',W',3], depth [H',W'], weights [H',W',S], feats_out [H',W',512],
     feats_out_3d [H',W',S*512] (skipped with the extension flag feats_out_3d=False)."""
     N_rays = ray_batch["ray_o"].shape[0]
+    Hs, Ws = _strided_hw(ray_sampler, render_stride)
     acc = _render_chunks(ray_batch, model, projector, chunk_size, N_samples, inv_uniform,
                          N_importance, det, white_bkgd, featmaps, deep_semantics, ret_alpha,
-                         single_net, 0, N_rays, feats_out_3d)
-    Hs, Ws = _strided_hw(ray_sampler, render_stride)
+                         single_net, 0, N_rays, feats_out_3d, row_width=Ws if N_rays == Hs * Ws else None)
     return _merge(acc, Hs, Ws)
 
 
@@ -172,9 +178,10 @@ def render_rank_tiles(rank, G, ray_sampler, ray_batch, model, projector, chunk_s
     Hs, Ws = _strided_hw(ray_sampler, render_stride)
     rows, parts = shard_rows(Hs, G)
     r0, r1 = parts[rank]
+    extra = {} if render_fn is not None or ray_batch["ray_o"].shape[0] != Hs * Ws else {"row_width": Ws}
     fn = render_fn or _render_chunks
     acc = fn(ray_batch, model, projector, chunk_size, N_samples, inv_uniform, N_importance, det,
-             white_bkgd, featmaps, deep_semantics, ret_alpha, single_net, r0 * Ws, r1 * Ws, False)
+             white_bkgd, featmaps, deep_semantics, ret_alpha, single_net, r0 * Ws, r1 * Ws, False, **extra)
     dev = ray_batch["ray_o"].device
     layout = tile_layout(N_samples, N_importance, ret_alpha, deep_semantics is not None, gather_weights)
     tiles = OrderedDict()

@@ -124,7 +124,7 @@ def raw2outputs(raw, z_vals, mask, white_bkgd=False):
                         ("mask", rmask > 0.5), ("alpha", alpha), ("z_vals", z_vals)])
 
 
-def _gnt_pass(net, projector, sv, pts, z_vals, ray_d, ret_alpha, want_3d=True):
+def _gnt_pass(net, projector, sv, pts, z_vals, ray_d, ret_alpha, want_3d=True, row_hint=None):
     """One coarse/fine pass on the fused path (gpn_render_pass): the projector runs fused into the
     network's first stage (no [R,S,V,35] tensor), the semantic aggregation samples the NHWC
     deep-semantic maps itself (no [R,S,V,512] tensor)."""
@@ -133,7 +133,7 @@ def _gnt_pass(net, projector, sv, pts, z_vals, ray_d, ret_alpha, want_3d=True):
         deep_map = dict(map=sv.deep, proj=sv.proj, img_h=sv.img_h, img_w=sv.img_w)
     out, depth, feats_out, feats_out_3d = net.run(
         None, None, None, pts, ray_d, z_vals=z_vals if ret_alpha else None,
-        deep_map=deep_map, want_sem3d=want_3d, proj=projector.fused_args(sv))
+        deep_map=deep_map, want_sem3d=want_3d, proj=projector.fused_args(sv), row_hint=row_hint)
     if ret_alpha:
         rgb, weights = out[:, 0:3], out[:, 3:]
     else:
@@ -172,10 +172,14 @@ def render_rays(
     sv = projector.prepare(ray_batch["camera"], ray_batch["src_rgbs"], ray_batch["src_cameras"],
                            featmaps, ref_deep_semantics)
     fused = model_type == "gnt" and hasattr(model.net_coarse, "run")
+    # optional key (not in the reference's ray_batch): (rays per image row, column of ray 0) when the rays of this
+    # batch are consecutive pixels in row-major order -- render_single_image sets it per chunk.  A scheduling
+    # hint for the semantic pass only; results do not depend on it.
+    row_hint = ray_batch.get("pixel_row")
 
     if fused:
         ret["outputs_coarse"] = _gnt_pass(model.net_coarse, projector, sv, pts, z_vals, ray_d,
-                                          ret_alpha, feats_out_3d)
+                                          ret_alpha, feats_out_3d, row_hint)
     else:
         rgb_feat, deep, ray_diff, mask = projector.compute(
             pts, ray_batch["camera"], ray_batch["src_rgbs"], ray_batch["src_cameras"],
@@ -203,7 +207,7 @@ def render_rays(
         net = model.net_coarse if single_net else model.net_fine
         if hasattr(net, "run"):
             ret["outputs_fine"] = _gnt_pass(net, projector, sv, pts, z_vals, ray_d, True,
-                                            feats_out_3d)
+                                            feats_out_3d, row_hint)
         else:
             rgb_feat, deep, ray_diff, mask = projector.compute(
                 pts, ray_batch["camera"], ray_batch["src_rgbs"], ray_batch["src_cameras"],

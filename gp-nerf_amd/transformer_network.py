@@ -203,10 +203,12 @@ class GNT(nn.Module):
 
     # ------------------------------------------------------------------ kernels
     def run(self, rgb_feat, ray_diff, mask, pts, ray_d, z_vals=None, deep_dense=None, deep_map=None,
-            want_sem3d=True, proj=None, return_mask=False):
+            want_sem3d=True, proj=None, return_mask=False, row_hint=None):
         """Shared driver of `forward` (materialised deep_sem) and render_rays' fused path (deep maps).
 
         deep_map: dict(map=[V,Hs,Ws,512] NHWC, proj=[V,4,4], img_h, img_w) or None.
+        row_hint: (rays per image row, column of ray 0) when the rays are consecutive pixels in row-major order
+        (gpn_sem_args_t.ray_row_*: scheduling hint of the semantic pass, results do not depend on it).
         proj: a gpn_project_args_t of the source views (Projector.fused_args) -- the projector then runs
         fused into the network's first stage (gpn_render_pass) and rgb_feat / ray_diff / mask are None.
         Returns out [R,3+S], depth [R] or None, sem_feat [R,512] or None, sem_feat_3d or None
@@ -262,6 +264,8 @@ class GNT(nn.Module):
                 sem.deep_map, sem.deep_h, sem.deep_w = _lib.ptr(m), m.shape[1], m.shape[2]
                 sem.xyz, sem.proj = _lib.ptr(pts), _lib.ptr(deep_map["proj"])
                 sem.img_h, sem.img_w = deep_map["img_h"], deep_map["img_w"]
+                if row_hint is not None:
+                    sem.ray_row_width, sem.ray_row_offset = int(row_hint[0]), int(row_hint[1])
         semp = C.byref(sem) if sem is not None else None
         if proj is None:
             _lib.check(_lib.lib().gpn_gnt_forward(

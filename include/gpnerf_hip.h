@@ -320,6 +320,13 @@ typedef struct {
   /* attn_fc[2] of every view layer (weight [C,8] row-major, bias [C]): logits = W . hidden + b */
   const float* attn2_w[GPN_MAX_DEPTH];
   const float* attn2_b[GPN_MAX_DEPTH];
+  /* Scheduling hint only (results do not depend on it; 0 = unknown): the R rays are consecutive pixels of an
+   * image in row-major order, ray_row_width rays per image row, ray 0 sitting at column ray_row_offset of its
+   * row (render_single_image's chunks, reference render_image.py:39-47).  With it every XCD works on a 2-D
+   * patch of the image -- rows of one column strip share texel rows of the deep-semantic maps -- instead of
+   * a 1-D run of rays: measured HBM fetch of the pass 2.31 -> 1.38 GB at the north-star shape, same time.
+   * Used when both are multiples of 64 / 8 and the chunk spans at least two rows. */
+  int ray_row_width, ray_row_offset;
 } gpn_sem_args_t;
 
 /* Deep-semantic aggregation of Attention2D (:90), Attention (:180-184) and GNT.forward (:335-336)

@@ -68,7 +68,7 @@ HBM_PEAK_GBPS = 8000.0
 # what a bare copy kernel reaches on this GPU for k_view_attn's access shape (random 256-byte rows,
 # read + written; tools/micro/reqbench.hip, profiles/r01_reqbench.txt); sequential read-only: 6250
 RANDOM_ROW_RW_CEILING_GBPS = 4700.0
-TRAFFIC_FILE = "profiles/r02_pmc_traffic.json"  # tools/profile_round.sh r02 + tools/profile_collect.py r02
+TRAFFIC_FILE = "profiles/r03_pmc_traffic.json"  # tools/profile_round.sh r03 + tools/profile_collect.py r03
 
 RIGS = {
     # 15 cm / 5 cm offsets, 2 degrees of yaw per view, depth 0.1-10 m (mask mean ~0.41)
@@ -126,7 +126,7 @@ def mfma_peak(precision):
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 as the
     gfx950 correction + WRITE_SIZE, separate runs of this same command).  None if the file is missing."""
-    for name in (TRAFFIC_FILE, "profiles/r02a_pmc_traffic.json"):
+    for name in (TRAFFIC_FILE, "profiles/r02_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, name)) as f:
                 return json.load(f)[kernel]["hbm_bytes_per_launch"], name

@@ -1,7 +1,7 @@
 """Summary of tools/pmc_util.sh: per kernel (mean over its launches) the launch time, the effective clock
 (GRBM_GUI_ACTIVE / 8 XCDs / time), the share of the SIMD cycles in which the MFMA pipe is busy
 (SQ_VALU_MFMA_BUSY_CYCLES / (cycles x 1024 SIMDs)) and the split of the wave cycles into issuing /
-stalled at issue / waiting (quad-cycle counters, MI355X_MICROARCH.md).  Writes profiles/r02_pmc_util.txt."""
+stalled at issue / waiting (quad-cycle counters, MI355X_MICROARCH.md).  Writes profiles/r03_pmc_util.txt."""
 import collections
 import csv
 import glob
@@ -10,7 +10,7 @@ import os
 out = ["# rocprofv3 --pmc pass over `bench.py --only-timed --steps 2 --warmup 1 --precision <mode>` (tools/pmc_util.sh)",
        "# mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs); clock = GRBM_GUI_ACTIVE / 8 / launch time",
        "# (reads high on launches well under 0.3 ms); wave-cycle split: issuing / stalled at issue / waiting (s_waitcnt, barrier)"]
-for mode in ("fp32", "bf16x3"):
+for mode in ("fp32", "bf16x3", "bf16"):
     fs = glob.glob("gpurun_out/pmc_util_%s/*/*counter_collection.csv" % mode)
     if not fs:
         continue
@@ -36,5 +36,5 @@ for mode in ("fp32", "bf16x3"):
             name[:28], len(d["ns"]), m["ns"] / 1e3, cyc / m["ns"], m["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0),
             m["SQ_ACTIVE_INST_ANY"] / wave, m["SQ_WAIT_INST_ANY"] / wave, m["SQ_WAIT_ANY"] / wave, m["SQ_INSTS_MFMA"])))
     out += [r for _, r in sorted(rows, reverse=True)]
-open("profiles/r02_pmc_util.txt", "w").write("\n".join(out) + "\n")
+open("profiles/r03_pmc_util.txt", "w").write("\n".join(out) + "\n")
 print("\n".join(out))

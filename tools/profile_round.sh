@@ -4,7 +4,7 @@
 # modes (fp32 = the headline), their bench lines, HBM bytes per kernel from separate FETCH_SIZE / WRITE_SIZE
 # PMC passes (both modes), and the same three passes for the standalone projector leg (k_project_deep).
 # Usage (on the GPU box): bash tools/profile_round.sh <tag>
-tag=${1:-r02}
+tag=${1:-r03}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$tag
 rm -rf $O

@@ -541,7 +541,7 @@ def main():
     if rank == 0:
         detail = dict({"headline": dict(head, stage_ms_one_step=stages), "legs": legs,
                        "full_image": full_image, "cpu_baseline": cpu}, **others)
-        legs_file = write_detail(detail)
+        legs_file = None if a.only_timed else write_detail(detail)  # (profiling runs keep the last full run's file)
         line = {
             "metric": "rays_per_sec", "value": head["value"], "unit": "rays/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": head["ms_per_step"],

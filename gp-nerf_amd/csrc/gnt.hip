@@ -2446,19 +2446,6 @@ k_ray1(gpn_ray_layer_t Lw, const float* x_in, int R, int S, float* x_out,
 #ifndef SEM_WAVES_PER_SIMD
 #define SEM_WAVES_PER_SIMD 4
 #endif
-#ifndef SEM_PREFETCH
-#define SEM_PREFETCH 0  // 1: taps of the next (sample, view) in flight (+40 VGPRs: measured slower than 4 waves per SIMD)
-#endif
-#if SEM_PREFETCH
-#error "SEM_PREFETCH=1 is stale: the prefetch pipeline predates `live = vis ? vis : (all_views & tab.hit)` and would blend the wrong taps"
-#endif
-#ifndef SEM_HS
-#define SEM_HS 0  // 1: the 8 x DEPTH hidden values of a (sample, view) pair come in through SCALAR loads (the pair is
-                  // wave-uniform: one wave = one ray) and enter the packed fmas as SGPR operands -- no LDS round
-                  // trip for them (the LDS pipe was the kernel's busiest unit: 32 ds_read_b128 per pair, half
-                  // of them broadcast reads of these values); 0: vector load -> LDS slot -> broadcast reads
-#endif
-typedef const __attribute__((address_space(4))) float* sem_cfp;
 __device__ __forceinline__ float rl_f(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
@@ -2546,19 +2533,11 @@ k_sem(gpn_sem_args_t a, int strip_groups) {
       b = a.attn2_b[l] ? a.attn2_b[l][lane] : 0.0f;
     }
     if (wave == 0) {  // one wave fills the image (every wave would write the same values)
-#if SEM_HS
-      // one 16-byte unit per lane, layer and half of the hidden values: (w[l][4h], .., w[l][4h+3])
-      if (l < DEPTH) {
-        st4(sW + ((l * 2 + 0) * 64 + lane) * 4, w0 * f4_splat(LOG2E_F));
-        st4(sW + ((l * 2 + 1) * 64 + lane) * 4, w1 * f4_splat(LOG2E_F));
-      }
-#else
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         sW[(((l >> 1) * 4 + (k >> 1)) * 64 + lane) * 4 + (k & 1) * 2 + (l & 1)] = w0[k] * LOG2E_F;
         sW[(((l >> 1) * 4 + 2 + (k >> 1)) * 64 + lane) * 4 + (k & 1) * 2 + (l & 1)] = w1[k] * LOG2E_F;
       }
-#endif
     }
     a2b[l >> 1][l & 1] = b;
   }
@@ -2592,9 +2571,9 @@ k_sem(gpn_sem_args_t a, int strip_groups) {
     if (!dense) t_.hit = (unsigned)__ballot(hit_);
     return t_;
   };
-  // the 8 x 16 bytes a lane needs of one (sample, view): four taps x this lane's 8 channels.
-  // Issued one pair ahead (across the sample boundary too), so a wave always has the next pair's
-  // 8 KB in flight while it rebuilds the current pair's attention weights.
+  // the 8 x 16 bytes a lane needs of one (sample, view): four taps x this lane's 8 channels; requested right
+  // before the pair's weight rebuild, which runs while they are in flight (requesting them a pair earlier costs
+  // 32 registers, i.e. the fourth wave per SIMD, or the L1 sharing of the lock-stepped rays: DESIGN.md 7, 7b)
   f4 tp[8];
   auto fetch_taps = [&](const TapTab& t_, int v_) {
     const unsigned s00 = rl_u(t_.o00, v_), s01 = rl_u(t_.o01, v_), s10 = rl_u(t_.o10, v_), s11 = rl_u(t_.o11, v_);
@@ -2611,10 +2590,6 @@ k_sem(gpn_sem_args_t a, int strip_groups) {
   TapTab tab_next = tap_table((size_t)rc * S);
 #pragma unroll
   for (int k = 0; k < 8; ++k) tp[k] = f4_zero();
-  if (!dense && SEM_PREFETCH) {
-    const unsigned v0 = live_of_mask(mv_next);
-    fetch_taps(tab_next, __builtin_ctz(v0 != 0 ? v0 : all_views));
-  }
   for (int s = 0; s < S; ++s) {
     const size_t n = (size_t)rc * S + s;
     // per-sample state, every load issued before the first use: softmax stats and mean ray
@@ -2640,19 +2615,12 @@ k_sem(gpn_sem_args_t a, int strip_groups) {
     // an all-masked sample takes the uniform weight over EVERY view, but a view whose four taps all
     // lie outside its map contributes exact zeros (grid_sample zero padding): skipped, same bits
     unsigned live = vis != 0 ? vis : (all_views & tab.hit);
-    unsigned live_n = 0;  // live views of the next sample
-    if (s + 1 < S) {
-      const unsigned vn = live_of_mask(mv_next);
-      live_n = vn != 0 ? vn : (all_views & tab_next.hit);
-    }
     // hidden layer of attn_fc for all DEPTH layers of a (sample, view): 8*DEPTH floats, one per lane,
     // fetched one view ahead; every lane needs all of them, so they go through an LDS slot of the
     // wave and come back as broadcast reads (same address in all lanes: conflict free)
-    [[maybe_unused]] float hvn = 0.f;
-#if !SEM_HS
+    float hvn = 0.f;
     if (vis != 0 && lane < DEPTH * 8)
       hvn = __builtin_nontemporal_load(a.hidden + (n * V + __builtin_ctz(live)) * (DEPTH * 8) + lane);
-#endif
     // bias - log-sum-exp, in log2 units: the constant part of every logit of this sample
 #pragma unroll
     for (int p = 0; p < LP; ++p) bl[p] = (a2b[p] - bl[p]) * (f2){LOG2E_F, LOG2E_F};
@@ -2663,13 +2631,11 @@ k_sem(gpn_sem_args_t a, int strip_groups) {
     while (live) {
       const int v = __builtin_ctz(live);
       live &= live - 1;
-#if !SEM_HS
       if (vis != 0) {
         if (lane < DEPTH * 8) sH[wave][hslot] = hvn;
         if (live && lane < DEPTH * 8)
           hvn = __builtin_nontemporal_load(a.hidden + (n * V + __builtin_ctz(live)) * (DEPTH * 8) + lane);
       }
-#endif
       f4 d0, d1;
       if (dense) {
         const float* dd = a.deep_dense + (n * V + v) * GPN_SEM;
@@ -2678,50 +2644,14 @@ k_sem(gpn_sem_args_t a, int strip_groups) {
       } else {
         // this view's tap weights: wave-uniform (scalar registers); out-of-map taps carry weight 0
         const float tnw_w = rl_f(tab.wnw, v), tne_w = rl_f(tab.wne, v), tsw_w = rl_f(tab.wsw, v), tse_w = rl_f(tab.wse, v);
-        if (!SEM_PREFETCH) fetch_taps(tab, v);
+        fetch_taps(tab, v);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           d0[c] = gpn_bilerp4(tp[0][c], tp[2][c], tp[4][c], tp[6][c], tnw_w, tne_w, tsw_w, tse_w);
           d1[c] = gpn_bilerp4(tp[1][c], tp[3][c], tp[5][c], tp[7][c], tnw_w, tne_w, tsw_w, tse_w);
         }
-        // next pair: the next live view of this sample, else the first live view of the next one
-        if (SEM_PREFETCH) {
-          if (live) fetch_taps(tab, __builtin_ctz(live));
-          else if (live_n) fetch_taps(tab_next, __builtin_ctz(live_n));
-        }
       }
       float w3 = w3u, w2 = w2u;
-#if SEM_HS
-      if (vis != 0) {
-        // logits of this lane's channel group in all layers: attn_fc[2] row . hidden + bias (:66-70); the
-        // hidden values are wave-uniform -> scalar loads, SGPR-pair operands of the packed fmas (even and
-        // odd hidden values of ONE layer in the two halves, summed before the exponential);
-        // softmax weight = 2^(logit - lse) in log2 units
-        // (the element offset is wave-uniform by construction; readfirstlane tells the compiler so, which is what
-        // turns these loads into s_load_dwordx2 and the operands into SGPR pairs)
-        const unsigned long long ho = (unsigned long long)((n * V + v) * (DEPTH * 8));
-        const unsigned long long hou =
-            (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ho) |
-            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ho >> 32)) << 32);
-        sem_cfp hs = (sem_cfp)a.hidden + hou;
-        w3 = 0.f, w2 = 0.f;
-#pragma unroll
-        for (int l = 0; l < DEPTH; ++l) {
-          f2 lg = (f2){bl[l >> 1][l & 1], 0.f};
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
-            const f4 w = ld4(sW + ((l * 2 + hh) * 64 + lane) * 4);
-            const f2 h0 = (f2){hs[8 * l + 4 * hh + 0], hs[8 * l + 4 * hh + 1]};
-            const f2 h1 = (f2){hs[8 * l + 4 * hh + 2], hs[8 * l + 4 * hh + 3]};
-            lg = w.lo * h0 + lg;
-            lg = w.hi * h1 + lg;
-          }
-          const float at = __builtin_amdgcn_exp2f(lg.x + lg.y);
-          w3 += at;
-          w2 = ab[l >> 1][l & 1] * at + w2;
-        }
-      }
-#else
       if (vis != 0) {
         // logits of this lane's channel group in all layers: attn_fc[2] row . hidden + bias (:66-70),
         // two layers per packed fma; softmax weight = 2^(logit - lse) in log2 units
@@ -2745,7 +2675,6 @@ k_sem(gpn_sem_args_t a, int strip_groups) {
         }
         w3 = w3p.x + w3p.y, w2 = w2p.x + w2p.y;
       }
-#endif
       // weights of the two channel groups this lane's channels belong to
       const float w3A = __shfl(w3, lane >> 1), w3B = __shfl(w3, 32 + (lane >> 1));
       const float w2A = __shfl(w2, lane >> 1), w2B = __shfl(w2, 32 + (lane >> 1));

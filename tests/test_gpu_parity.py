@@ -127,6 +127,40 @@ def test_projector_bit_exact(dev, golden):
     assert rel(ray_diff, g["ray_diff"]) < 1e-5
 
 
+def test_projector_deep_gather_unit_order_is_bit_identical(dev):
+    """Projector.compute's 512-channel gather at a size that takes the (ray block, view) unit order with the
+    sliding texel window (csrc/projector.hip: needs the samples-per-ray hint, >= 16 units and a full grid),
+    against the same points handed over WITHOUT the hint ([N,1,3]: the slab order with plain four-tap loads):
+    every output identical bit for bit.  600 rays (two whole ray blocks + a ragged one, a ragged last run) x
+    24 samples x 10 views; the window's cases all occur: same texels, one column further, jumps, rows
+    outside the map (zero padding)."""
+    from gp_nerf_amd import synth
+    from gp_nerf_amd.projection import Projector
+    K = synth.scaled_intrinsics(synth.SCANNET_K, 0.5, 0.5)
+    sc = synth.Scene(120, 160, 10, K, (0.1, 6.0), seed=77)
+    R, S = 603, 24
+    rb = to(dev, sc.ray_batch(start=160 * 40 + 3, count=R))
+    z = 1.0 / torch.linspace(1.0 / 0.1, 1.0 / 6.0, S, device=dev)
+    pts = (rb["ray_o"][:, None] + z[None, :, None] * rb["ray_d"][:, None]).contiguous()
+    P = Projector(dev)
+    fm, deep = sc.featmaps.to(dev), sc.deep_semantics.to(dev)
+    a = P.compute(pts, rb["camera"], rb["src_rgbs"], rb["src_cameras"], fm, deep)
+    b = P.compute(pts.reshape(R * S, 1, 3), rb["camera"], rb["src_rgbs"], rb["src_cameras"], fm, deep)
+    torch.cuda.synchronize()
+    V = 10
+    assert tuple(a[1].shape) == (R, S, V, 512) and 0.1 < float(a[3].mean()) < 0.9
+    for x, y, name in zip(a, b, ("rgb_feat", "deep", "ray_diff", "mask")):
+        assert torch.equal(x.reshape(y.shape).view(torch.int32), y.view(torch.int32)), name
+    # and against the oracle on a slice (the full tensor is 300 MB: rays 250..262 straddle two ray blocks)
+    c = {k: v.cpu() for k, v in rb.items()}
+    o = oracle.projector.compute(pts[250:262].cpu(), c["camera"], c["src_rgbs"], c["src_cameras"], sc.featmaps,
+                                 sc.deep_semantics)
+    # (torch's CPU bmm rounds small batches differently, DESIGN.md section 5: compare where the masks agree)
+    same = (o[3] == a[3][250:262].cpu()).all(dim=-1).all(dim=-1).all(dim=-1)
+    assert float(same.float().mean()) > 0.8
+    assert float((a[1][250:262].cpu()[same] - o[1][same]).abs().max()) < 1e-5
+
+
 def test_projector_reused_across_images(dev):
     """One Projector serves every image of an eval loop (reference eval_gpnerf.py:97-118).  The camera
     tensors of successive images have the same shape and _version 0, and the caching allocator hands a

@@ -65,9 +65,6 @@ N_SAMPLES, N_IMPORTANCE, VIEWS = 48, 16, 10
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
 BF16_MATRIX_PEAK_TFLOPS = 2500.0  # dense; a bf16x3 product costs three MFMA flops per algorithmic flop
 HBM_PEAK_GBPS = 8000.0
-# what a bare copy kernel reaches on this GPU for k_view_attn's access shape (random 256-byte rows,
-# read + written; tools/micro/reqbench.hip, profiles/r01_reqbench.txt); sequential read-only: 6250
-RANDOM_ROW_RW_CEILING_GBPS = 4700.0
 TRAFFIC_FILE = "profiles/r03_pmc_traffic.json"  # tools/profile_round.sh r03 + tools/profile_collect.py r03
 
 RIGS = {
@@ -103,13 +100,9 @@ def view_attn_flops_per_point(V):
 
 FF_FLOPS_PER_POINT = 2 * 2 * 64 * 256  # fc1 + fc2 of one FeedForward (the FF share of 81,920 / 98,304)
 
-# MFMA flops k_view_attn executes (MAC = 2; every bf16x3 product counts its three MFMAs).
-# bf16x3 (folded weights): per computed pair (Wv Wk) 8192 + pos_fc[2] 1024 + (A0 Wk | A0 P2) 1152 +
-# attn_fc[2] 1024 = 11392, x3; + fp32 pos_fc[0] 64.  Per point q_fc + out_fc + A0 q = 17408, x3.
-# fp32 (same folded products, one fp32 MFMA flop per algorithmic flop): 11392 + 64 per pair, 17408 per point.
-VIEW_EXEC_FLOPS_PER_PAIR = {"bf16x3": 3 * 11392 + 64, "fp32": 11392 + 64}
-VIEW_EXEC_FLOPS_PER_POINT = {"bf16x3": 3 * 17408, "fp32": 17408}
-# the same as ALGORITHMIC flops of the kernel (one flop per fp32 product, whatever the MFMA type)
+# ALGORITHMIC flops of k_view_attn (MAC = 2; one flop per fp32 product, whatever the MFMA type; folded weights):
+# per computed pair (Wv Wk) 8192 + pos_fc[2] 1024 + (A0 Wk | A0 P2) 1152 + attn_fc[2] 1024 = 11392, + fp32 pos_fc[0]
+# 64; per point q_fc + out_fc + A0 q = 17408.  (A bf16x3 product issues three MFMAs per flop: `mult` in rooflines.)
 VIEW_ALG_FLOPS_PER_PAIR = 11392 + 64
 VIEW_ALG_FLOPS_PER_POINT = 17408
 QPOS_FLOPS_PER_POINT = 2 * (192 * 64 + 64 * 64)  # q MLP on [q | emb_pt | emb_ray] (190 of the 192 inputs are real)

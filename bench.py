@@ -308,11 +308,21 @@ def main():
                     dist.all_gather_into_tensor(host, tile.cpu())
                     gathered.copy_(host)
                 else:
-                    dist.all_gather_into_tensor(gathered, tile)
+                    # asynchronous: RCCL runs the gather of step k on its own stream while the kernels of step
+                    # k + 1 run on the launch stream (a chunk loop over an image pipelines the same way); the
+                    # launch stream waits for it only before the next gather reuses `gathered`, or at the fence --
+                    # every collective still completes INSIDE the timed region (fence() waits for the last one)
+                    if pending:
+                        pending.pop().wait()
+                    pending.append(dist.all_gather_into_tensor(gathered, tile, async_op=True))
             return ret
         return step
 
+    pending = []  # the all-gather in flight (at most one)
+
     def fence():
+        while pending:
+            pending.pop().wait()
         torch.cuda.synchronize()
         if multi:
             dist.barrier()
@@ -556,7 +566,8 @@ def main():
             line["rccl_world"] = rccl_world
             line["backend"] = dist.get_backend()
             line["rank_ms_per_step"] = rank_ms
-            line["collective"] = "all_gather_into_tensor of [rays, %d] fp32 tiles inside every timed step" % tile_w
+            line["collective"] = ("all_gather_into_tensor of [rays, %d] fp32 tiles per step, asynchronous (overlaps the "
+                                  "next step's kernels), all completed inside the timed region" % tile_w)
         text = json.dumps(round_floats(line))
         for drop in ("stage_ms_one_step", "legs", "other_modes", "path_vs_reference_flops"):  # never again an unparseable line
             if len(text) > 4000:

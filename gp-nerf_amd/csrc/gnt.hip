@@ -2548,17 +2548,22 @@ k_sem(gpn_sem_args_t a, int strip_groups) {
   // Bilinear taps of a sample in every source view, one view per lane (the arithmetic of the
   // projector, proj_common.h): element offsets inside the view's map (clamped to valid texels) and
   // the four weights, zero for taps outside the map (grid_sample's zero padding).
+  // The table is made for a BATCH of SB = 64 / V consecutive samples at once, lane = (sample of the batch, view):
+  // the projection arithmetic runs once per batch with SB * V of the 64 lanes busy instead of once per sample
+  // with V of them (it was 148 of the ~310 instructions a sample costs outside its view loop).
   struct TapTab {
     unsigned o00, o01, o10, o11;
     float wnw, wne, wsw, wse;
-    unsigned hit;  // views with a tap inside their map (wave-uniform; the others sample exact zeros)
   };
-  auto tap_table = [&](size_t n_) {
-    TapTab t_ = {0, 0, 0, 0, 0.f, 0.f, 0.f, 0.f, 0xffffffffu};
+  const int SB = min(64 / V, 8), jl = lane / V, vl = lane - jl * V;  // (V <= GPN_MAX_VIEWS = 32: SB >= 2)
+  const bool tl = jl < SB;                                         // lanes that carry a (sample, view) of the batch
+  auto batch_row = [&](int s0_) { return (size_t)rc * S + min(s0_ + jl, S - 1); };  // this lane's sample (clamped)
+  unsigned long long hit64 = ~0ull;  // views with a tap inside their map, SB fields of V bits (wave-uniform)
+  auto tap_table = [&](float px, float py, float pz) {
+    TapTab t_ = {0, 0, 0, 0, 0.f, 0.f, 0.f, 0.f};
     bool hit_ = false;
-    if (!dense && lane < V) {
-      const float px = a.xyz[n_ * 3 + 0], py = a.xyz[n_ * 3 + 1], pz = a.xyz[n_ * 3 + 2];
-      const GpnPix pp = gpn_project(sP + lane * 12, px, py, pz);
+    if (!dense && tl) {
+      const GpnPix pp = gpn_project(sP + vl * 12, px, py, pz);
       const GpnTaps t = gpn_taps(pp.px, pp.py, a.img_h, a.img_w, a.deep_h, a.deep_w);
       const int x0 = min(max(t.x0, 0), a.deep_w - 1), x1 = min(max(t.x0 + 1, 0), a.deep_w - 1);
       const int y0 = min(max(t.y0, 0), a.deep_h - 1), y1 = min(max(t.y0 + 1, 0), a.deep_h - 1);
@@ -2568,36 +2573,48 @@ k_sem(gpn_sem_args_t a, int strip_groups) {
       t_.wsw = (t.vy1 && t.vx0) ? t.sw : 0.0f, t_.wse = (t.vy1 && t.vx1) ? t.se : 0.0f;
       hit_ = (t.vy0 || t.vy1) && (t.vx0 || t.vx1);
     }
-    if (!dense) t_.hit = (unsigned)__ballot(hit_);
+    if (!dense) hit64 = __ballot(hit_);
     return t_;
   };
   // the 8 x 16 bytes a lane needs of one (sample, view): four taps x this lane's 8 channels; requested right
   // before the pair's weight rebuild, which runs while they are in flight (requesting them a pair earlier costs
   // 32 registers, i.e. the fourth wave per SIMD, or the L1 sharing of the lock-stepped rays: DESIGN.md 7, 7b)
   f4 tp[8];
-  auto fetch_taps = [&](const TapTab& t_, int v_) {
-    const unsigned s00 = rl_u(t_.o00, v_), s01 = rl_u(t_.o01, v_), s10 = rl_u(t_.o10, v_), s11 = rl_u(t_.o11, v_);
+  auto fetch_taps = [&](const TapTab& t_, int v_, int l_) {  // l_: the lane that holds (sample, view v_)
+    const unsigned s00 = rl_u(t_.o00, l_), s01 = rl_u(t_.o01, l_), s10 = rl_u(t_.o10, l_), s11 = rl_u(t_.o11, l_);
     const float* dm = a.deep_map + (size_t)v_ * a.deep_h * rs + (unsigned)c4;
     tp[0] = ld4(dm + s00), tp[1] = ld4(dm + s00 + 256), tp[2] = ld4(dm + s01), tp[3] = ld4(dm + s01 + 256);
     tp[4] = ld4(dm + s10), tp[5] = ld4(dm + s10 + 256), tp[6] = ld4(dm + s11), tp[7] = ld4(dm + s11 + 256);
   };
-  auto live_of_mask = [&](float m_) {
-    const unsigned vis_ = (unsigned)__ballot(m_ != 0.0f);
-    return vis_;
-  };
-  // visibility bits: lane v reads the mask of view v, one sample ahead
-  float mv_next = lane < V ? a.mask[(size_t)rc * S * V + lane] : 0.0f;
-  TapTab tab_next = tap_table((size_t)rc * S);
+  // mask and sample positions of a batch are loaded one batch ahead (lane = (sample of the batch, view))
+  float mv_next = tl ? a.mask[batch_row(0) * V + vl] : 0.0f;
+  float nx = 0.f, ny = 0.f, nz = 0.f;
+  if (!dense && tl) {
+    const float* xp = a.xyz + batch_row(0) * 3;
+    nx = xp[0], ny = xp[1], nz = xp[2];
+  }
+  TapTab tab = {0, 0, 0, 0, 0.f, 0.f, 0.f, 0.f};
+  unsigned long long vis64 = 0;
 #pragma unroll
   for (int k = 0; k < 8; ++k) tp[k] = f4_zero();
+  int jb = 0, lb = 0;  // sample inside the batch, first lane of its views
   for (int s = 0; s < S; ++s) {
     const size_t n = (size_t)rc * S + s;
-    // per-sample state, every load issued before the first use: softmax stats and mean ray
-    // attention of every layer, the next sample's mask and tap table
-    const float mv = mv_next;
-    if (s + 1 < S) mv_next = lane < V ? a.mask[(n + 1) * V + lane] : 0.0f;
-    const TapTab tab = tab_next;
-    if (s + 1 < S) tab_next = tap_table(n + 1);
+    if (jb == 0) {  // new batch: its table from the positions loaded a batch ago, then the next batch's loads
+      vis64 = __ballot(mv_next != 0.0f);
+      tab = tap_table(nx, ny, nz);
+      if (s + SB < S) {
+        mv_next = tl ? a.mask[batch_row(s + SB) * V + vl] : 0.0f;
+        if (!dense && tl) {
+          const float* xp = a.xyz + batch_row(s + SB) * 3;
+          nx = xp[0], ny = xp[1], nz = xp[2];
+        }
+      }
+    }
+    const unsigned vis = (unsigned)(vis64 >> lb) & all_views;
+    const unsigned hit = (unsigned)(hit64 >> lb) & all_views;
+    const int lane0 = lb;  // lane lane0 + v holds view v of this sample
+    if (++jb == SB) jb = 0, lb = 0; else lb += V;
     f2 bl[LP], ab[LP];
     const float* abp = a.abar + n * (DEPTH * 4);
     const float* stp = a.stats + n * (DEPTH * C64);
@@ -2611,10 +2628,9 @@ k_sem(gpn_sem_args_t a, int strip_groups) {
       ab[l >> 1][l & 1] = abv;
       bl[l >> 1][l & 1] = lse;
     }
-    const unsigned vis = live_of_mask(mv);
     // an all-masked sample takes the uniform weight over EVERY view, but a view whose four taps all
     // lie outside its map contributes exact zeros (grid_sample zero padding): skipped, same bits
-    unsigned live = vis != 0 ? vis : (all_views & tab.hit);
+    unsigned live = vis != 0 ? vis : hit;
     // hidden layer of attn_fc for all DEPTH layers of a (sample, view): 8*DEPTH floats, one per lane,
     // fetched one view ahead; every lane needs all of them, so they go through an LDS slot of the
     // wave and come back as broadcast reads (same address in all lanes: conflict free)
@@ -2643,8 +2659,9 @@ k_sem(gpn_sem_args_t a, int strip_groups) {
         d1 = ld4(dd + (unsigned)(c4 + 256));
       } else {
         // this view's tap weights: wave-uniform (scalar registers); out-of-map taps carry weight 0
-        const float tnw_w = rl_f(tab.wnw, v), tne_w = rl_f(tab.wne, v), tsw_w = rl_f(tab.wsw, v), tse_w = rl_f(tab.wse, v);
-        fetch_taps(tab, v);
+        const int tlane = lane0 + v;
+        const float tnw_w = rl_f(tab.wnw, tlane), tne_w = rl_f(tab.wne, tlane), tsw_w = rl_f(tab.wsw, tlane), tse_w = rl_f(tab.wse, tlane);
+        fetch_taps(tab, v, tlane);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           d0[c] = gpn_bilerp4(tp[0][c], tp[2][c], tp[4][c], tp[6][c], tnw_w, tne_w, tsw_w, tse_w);

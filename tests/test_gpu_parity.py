@@ -789,6 +789,39 @@ def test_gnt_forward_edge_shapes(dev, net, prec, R, S, V):
     assert all(bool(torch.isfinite(g_).all()) for g_ in got)
 
 
+@pytest.mark.parametrize("V,S,R", [(1, 5, 3), (3, 13, 11), (7, 16, 9), (11, 13, 24), (21, 7, 10), (32, 5, 17)])
+def test_sem_map_taps_equal_the_dense_rows_for_every_view_count(dev, net, V, S, R):
+    """k_sem makes its bilinear tap table once per batch of 64 / V samples (lane = sample of the batch x view):
+    every batch geometry -- 8 samples x 1 view ... 2 samples x 32 views, batches that end inside the ray, rays
+    whose last workgroup slot is empty -- through the fused pass (taps computed in the kernel from the NHWC maps)
+    against the SAME network on the rows Projector.compute gathered for the same points (dense [R,S,V,512] input
+    of GNT.forward): the blend arithmetic is the same, so feats_out / feats_out_3d agree to rounding of the
+    network stages in front (fused vs two-kernel first stage), and the rgb / weights outputs likewise."""
+    from gp_nerf_amd import synth
+    from gp_nerf_amd.projection import Projector
+    K = synth.scaled_intrinsics(synth.SCANNET_K, 0.3, 0.3)
+    sc = synth.Scene(72, 96, V, K, (0.1, 6.0), seed=300 + V, rig=dict(dx=0.04, dy=0.01, yaw_deg=-1.5))
+    rb = to(dev, sc.ray_batch(start=96 * 30 + 11, count=R))
+    z = 1.0 / torch.linspace(1.0 / 0.1, 1.0 / 6.0, S, device=dev)
+    pts = (rb["ray_o"][:, None] + z[None, :, None] * rb["ray_d"][:, None]).contiguous()
+    P = Projector(dev)
+    fm, deep = sc.featmaps.to(dev), sc.deep_semantics.to(dev)
+    rgb_feat, deep_rows, ray_diff, mask = P.compute(pts, rb["camera"], rb["src_rgbs"], rb["src_cameras"],
+                                                    featmaps=fm, deep_semantics=deep)
+    assert 0.02 < float(mask.mean()), "case lost its coverage"
+    net.precision = "fp32"
+    out_d, sem_d, sem3d_d = net(rgb_feat, deep_rows, ray_diff, mask, pts, rb["ray_d"])
+    sv = P.prepare(rb["camera"], rb["src_rgbs"], rb["src_cameras"], fm, deep)
+    out_m, _, sem_m, sem3d_m = net.run(None, None, None, pts, rb["ray_d"], z_vals=None,
+                                       deep_map=dict(map=sv.deep, proj=sv.proj, img_h=sv.img_h, img_w=sv.img_w),
+                                       want_sem3d=True, proj=P.fused_args(sv))
+    torch.cuda.synchronize()
+    errs = {"out": rel(out_m, out_d), "sem": rel(sem_m, sem_d), "sem3d": rel(sem3d_m, sem3d_d)}
+    print("sem map vs dense V=%d S=%d R=%d: %s (visible %.2f)" % (V, S, R, errs, float(mask.mean())))
+    assert max(errs.values()) < 2e-5, errs
+    assert all(bool(torch.isfinite(t).all()) for t in (out_m, sem_m, sem3d_m))
+
+
 @pytest.mark.parametrize("R,S,V", [(37, 48, 10), (21, 64, 7), (5, 96, 4)])
 def test_forward_equals_the_chain_of_stage_kernels(dev, net, prec, R, S, V):
     """Inside gpn_gnt_forward the feed-forward blocks and the q MLP run as later phases of the attention

@@ -246,7 +246,7 @@ def main():
                     help="skip the other arithmetic mode, the extra legs, the full-image run and the CPU baseline "
                          "(tools/profile_round.sh: the profiled kernels are then the timed workload only)")
     ap.add_argument("--leg", default=None, choices=("single_pass_64", "dense_visibility", "projector_standalone", "stress_shape",
-                                                 "scannet_eval_view", "chunk_16384"),
+                                                 "scannet_eval_view", "chunk_16384", "chunks_in_flight_2"),
                     help="run ONLY this leg as the timed workload (profiling aid; prints the leg's block)")
     a = ap.parse_args()
     if a.only_timed:
@@ -487,7 +487,7 @@ def main():
         legs = {name: run_leg(name, a, dev, scene, rb, net, model, projector, make_step, measure,
                               stage_breakdown, world, rank)
                 for name in ("single_pass_64", "dense_visibility", "projector_standalone", "stress_shape",
-                             "scannet_eval_view", "chunk_16384")}
+                             "scannet_eval_view", "chunk_16384", "chunks_in_flight_2")}
         net.precision = a.precision
 
     # secondary metric: seconds per full image through render_single_image, results
@@ -828,6 +828,34 @@ def run_leg(name, a, dev, scene, rb, net, model, projector, make_step, measure, 
                 out.setdefault(mode, {})["rays_%d" % big] = {"value": big / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt}
             del r, rbb
             torch.cuda.empty_cache()
+        return out
+    if name == "chunks_in_flight_2":
+        # the headline step (4096 rays, two passes) issued alternately on TWO streams, two different chunks: what the
+        # chunk loop of render_single_image does (render_image.CHUNK_STREAMS) -- the drain of every launch of one
+        # chunk runs under the other chunk's kernels.  Kernel durations overlap here, so this leg carries no roofline.
+        from gp_nerf_amd.render_ray import render_rays
+        out = {"workload": "the headline workload, %d-ray steps alternating over two HIP streams (two chunks in flight, "
+                           "as in render_single_image's chunk loop)" % CHUNK}
+        rbs = [ray_chunk(scene, r, 2, dev) for r in range(2)]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+
+        def step2(k):
+            with torch.cuda.stream(streams[k % 2]):
+                return render_rays(rbs[k % 2], model, scene.featmaps, scene.deep, projector, N_samples=N_SAMPLES,
+                                   inv_uniform=True, N_importance=N_IMPORTANCE, det=True, ret_alpha=True,
+                                   single_net=True)
+        for mode in ("fp32", "bf16x3"):
+            net.precision = mode
+            torch.cuda.synchronize()
+            keep = [step2(k) for k in range(4)]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                keep[k % 4] = step2(k)  # (results stay referenced until their stream has run them)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            out[mode] = {"value": CHUNK / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt}
+            del keep
         return out
     if name == "scannet_eval_view":
         # BASELINE.json configs[2]: one ScanNet-shaped evaluation view through the whole chain of

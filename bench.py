@@ -233,6 +233,12 @@ def cpu_baseline(scene, rb, n_rays):
                            "fp32 oracle, %.1f s" % (n_rays, dt)}
 
 
+# the legs of the default run (development aid: GPN_BENCH_LEGS=a,b runs a subset)
+LEG_NAMES = tuple(n for n in os.environ.get(
+    "GPN_BENCH_LEGS", "single_pass_64,dense_visibility,projector_standalone,stress_shape,scannet_eval_view,chunk_16384,"
+    "chunks_in_flight_2").split(",") if n)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -486,8 +492,7 @@ def main():
     if rank == 0 and world == 1 and not a.only_timed:
         legs = {name: run_leg(name, a, dev, scene, rb, net, model, projector, make_step, measure,
                               stage_breakdown, world, rank)
-                for name in ("single_pass_64", "dense_visibility", "projector_standalone", "stress_shape",
-                             "scannet_eval_view", "chunk_16384", "chunks_in_flight_2")}
+                for name in LEG_NAMES}
         net.precision = a.precision
 
     # secondary metric: seconds per full image through render_single_image, results
@@ -837,7 +842,8 @@ def run_leg(name, a, dev, scene, rb, net, model, projector, make_step, measure, 
         out = {"workload": "the headline workload, %d-ray steps alternating over two HIP streams (two chunks in flight, "
                            "as in render_single_image's chunk loop)" % CHUNK}
         rbs = [ray_chunk(scene, r, 2, dev) for r in range(2)]
-        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        from gp_nerf_amd.render_image import _side_streams
+        streams = _side_streams(dev, 2)  # the very streams the product's chunk loop uses in this process
 
         def step2(k):
             with torch.cuda.stream(streams[k % 2]):

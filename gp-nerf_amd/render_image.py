@@ -22,6 +22,8 @@ _SIDE_STREAMS = {}  # device index -> [torch.cuda.Stream]: the chunk loop's stre
 # one chunk runs under the other chunk's kernels (a 4096-ray chunk leaves ~5 % of the GPU idle at its 41 launch
 # boundaries: 10.5 -> 10.0 ms per chunk in fp32, tools/twostream.py).  1 = the reference's strictly serial loop.
 CHUNK_STREAMS = int(os.environ.get("GPN_CHUNK_STREAMS", "2"))
+# render_single_image copies every chunk's results to the host behind the chunk (_HostSink); 0: after the last chunk
+STREAM_TO_HOST = os.environ.get("GPN_STREAM_TO_HOST", "1") != "0"
 
 
 def _side_streams(dev, n):
@@ -33,7 +35,7 @@ def _side_streams(dev, n):
 
 def _render_chunks(ray_batch, model, projector, chunk_size, N_samples, inv_uniform, N_importance,
                    det, white_bkgd, featmaps, deep_semantics, ret_alpha, single_net, start, stop,
-                   feats_out_3d=True, row_width=None, streams=None):
+                   feats_out_3d=True, row_width=None, streams=None, sink=None):
     """Chunk loop (reference render_image.py:39-85) over rays [start, stop); results stay on the
     device: {'outputs_coarse': {k: [chunks]}, 'outputs_fine': ... or None}.
     row_width: rays per row when ray_batch holds the whole strided pixel grid in row-major order; every chunk
@@ -41,7 +43,9 @@ def _render_chunks(ray_batch, model, projector, chunk_size, N_samples, inv_unifo
     streams: chunks in flight (default CHUNK_STREAMS).  The first chunk runs on the caller's stream (it fills the
     per-image caches: repacked maps, cameras, folded weights); the others alternate over side streams that wait
     for it, and the caller's stream waits for all of them before this function returns -- to the caller the loop
-    is still one ordered piece of work on its stream, and the values do not depend on `streams`."""
+    is still one ordered piece of work on its stream, and the values do not depend on `streams`.
+    sink: a _HostSink; every chunk's results are then handed to it inside the chunk's stream context (it queues
+    their copies to the host right behind the chunk's kernels) instead of being collected on the device."""
     acc = OrderedDict([("outputs_coarse", OrderedDict()), ("outputs_fine", OrderedDict())])
     starts = list(range(start, stop, chunk_size))
     dev = ray_batch["ray_o"].device
@@ -71,6 +75,10 @@ def _render_chunks(ray_batch, model, projector, chunk_size, N_samples, inv_unifo
                               projector=projector, N_samples=N_samples, inv_uniform=inv_uniform,
                               N_importance=N_importance, det=det, white_bkgd=white_bkgd,
                               ret_alpha=ret_alpha, single_net=single_net, feats_out_3d=feats_out_3d)
+            if sink is not None:
+                sink.take(i - start, j - start, ret, cur if st is not None else None)
+        if sink is not None:
+            continue
         for lvl in ("outputs_coarse", "outputs_fine"):
             if ret[lvl] is None:
                 acc[lvl] = None
@@ -82,7 +90,7 @@ def _render_chunks(ray_batch, model, projector, chunk_size, N_samples, inv_unifo
                     acc[lvl].setdefault(k, []).append(v)
     for st in side:
         cur.wait_stream(st)
-    return acc
+    return acc if sink is None else sink
 
 
 def _strided_hw(ray_sampler, render_stride):
@@ -102,15 +110,101 @@ def _to_host(t, tag):
     nbytes = t.numel() * t.element_size()
     if nbytes > PINNED_KEEP_BYTES:
         return t.cpu(), None, False  # synchronous copy into a fresh pageable tensor; nothing retained
-    buf = _PINNED.get(tag)
-    if buf is None or buf.numel() < t.numel() or buf.dtype != t.dtype:
-        buf = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
-        _PINNED[tag] = buf
-    view = buf[: t.numel()].view(t.shape)
+    view = _pinned(tag, tuple(t.shape), t.dtype)
     view.copy_(t, non_blocking=True)
     done = torch.cuda.Event()
     done.record()
     return view, done, True
+
+
+def _finish(out, lvl, k, flat, Hs, Ws):
+    if k == "feats_out":
+        out[lvl][k] = flat.reshape((Hs, Ws, 512, -1)).squeeze()
+    else:
+        out[lvl][k] = flat.reshape((Hs, Ws, -1)).squeeze()
+
+
+class _HostSink:
+    """Host side of render_single_image's chunk loop: every chunk's outputs are copied into page-locked staging
+    buffers by asynchronous copies queued on the chunk's own stream right behind its kernels, and moved from there
+    into the result tensors by the host while the GPU renders the following chunks -- the copies and the host-side
+    moves of a 640x480 / stride-2 image (350 MB, 19 of 207 ms when done after the last chunk) disappear behind the
+    rendering, except the last chunk's.  Same values, same result structure as _merge.  Outputs too large to
+    stage (feats_out_3d of a big image, > PINNED_KEEP_BYTES) stay on the device and take _merge's path."""
+
+    def __init__(self, n_rays, dev):
+        self.n = n_rays
+        # the copies run on a stream of their own, behind an event of the chunk: the chunk's stream goes straight on
+        # to its next chunk (copies queued on the rendering streams themselves cost 12 of the 19 ms they were to save)
+        self.copy_stream = _side_streams(dev, 3)[2]
+        self.out = OrderedDict([("outputs_coarse", OrderedDict()), ("outputs_fine", OrderedDict())])
+        self.stage, self.big, self.pending = {}, OrderedDict(), []
+
+    def take(self, i, j, ret, reader_stream):
+        staged = []
+        ready = torch.cuda.Event()
+        ready.record()  # on the chunk's stream: behind its kernels
+        self.copy_stream.wait_event(ready)
+        for lvl in ("outputs_coarse", "outputs_fine"):
+            if ret[lvl] is None:
+                self.out[lvl] = None
+                continue
+            for k, v in ret[lvl].items():
+                if v is None or k == "random_sigma":
+                    continue
+                tag = (lvl, k)
+                if tag not in self.stage and tag not in self.big and k not in self.out[lvl]:  # first chunk
+                    shape = (self.n,) + tuple(v.shape[1:])
+                    if v.is_cuda and v[:1].numel() * self.n * v.element_size() > PINNED_KEEP_BYTES:
+                        self.big[tag] = []
+                    else:
+                        if v.is_cuda:
+                            self.stage[tag] = _pinned(tag, shape, v.dtype)
+                        self.out[lvl][k] = torch.empty(shape, dtype=v.dtype)
+                    if tag in self.big:
+                        self.out[lvl][k] = None  # (keeps the key order of the result)
+                if tag in self.big:
+                    if reader_stream is not None:
+                        v.record_stream(reader_stream)
+                    self.big[tag].append(v)
+                elif not v.is_cuda:
+                    self.out[lvl][k][i:j] = v
+                else:
+                    with torch.cuda.stream(self.copy_stream):
+                        self.stage[tag][i:j].copy_(v, non_blocking=True)
+                    staged.append((lvl, k, v))  # (v stays referenced until its copy has run: finish())
+        if staged:
+            done = torch.cuda.Event()
+            done.record(self.copy_stream)
+            self.pending.append((i, j, done, staged))
+
+    def finish(self, Hs, Ws):
+        for i, j, done, staged in self.pending:  # in chunk order, while later chunks are still being rendered
+            done.synchronize()
+            for lvl, k, _ in staged:
+                self.out[lvl][k][i:j].copy_(self.stage[(lvl, k)][i:j])
+        self.pending = []
+        late = [(lvl, k) + _to_host(torch.cat(vs, dim=0), (lvl, k)) for (lvl, k), vs in self.big.items()]
+        for lvl, k, host, done, shared in late:
+            if done is not None:
+                done.synchronize()
+            self.out[lvl][k] = host.clone() if shared else host
+        for lvl in ("outputs_coarse", "outputs_fine"):
+            if self.out[lvl] is not None:
+                for k in list(self.out[lvl]):
+                    _finish(self.out, lvl, k, self.out[lvl][k], Hs, Ws)
+        return self.out
+
+
+def _pinned(tag, shape, dtype):
+    numel = 1
+    for d in shape:
+        numel *= d
+    buf = _PINNED.get(tag)
+    if buf is None or buf.numel() < numel or buf.dtype != dtype:
+        buf = torch.empty(numel, dtype=dtype, pin_memory=True)
+        _PINNED[tag] = buf
+    return buf[:numel].view(shape)
 
 
 def _merge(acc, Hs, Ws):
@@ -129,11 +223,7 @@ def _merge(acc, Hs, Ws):
     for lvl, k, host, done, shared in staged:
         if done is not None:
             done.synchronize()
-        cat = host.clone() if shared else host
-        if k == "feats_out":
-            acc[lvl][k] = cat.reshape((Hs, Ws, 512, -1)).squeeze()
-        else:
-            acc[lvl][k] = cat.reshape((Hs, Ws, -1)).squeeze()
+        _finish(acc, lvl, k, host.clone() if shared else host, Hs, Ws)
     return acc
 
 
@@ -160,10 +250,12 @@ def render_single_image(
     feats_out_3d [H',W',S*512] (skipped with the extension flag feats_out_3d=False)."""
     N_rays = ray_batch["ray_o"].shape[0]
     Hs, Ws = _strided_hw(ray_sampler, render_stride)
+    on_gpu = ray_batch["ray_o"].is_cuda
     acc = _render_chunks(ray_batch, model, projector, chunk_size, N_samples, inv_uniform,
                          N_importance, det, white_bkgd, featmaps, deep_semantics, ret_alpha,
-                         single_net, 0, N_rays, feats_out_3d, row_width=Ws if N_rays == Hs * Ws else None)
-    return _merge(acc, Hs, Ws)
+                         single_net, 0, N_rays, feats_out_3d, row_width=Ws if N_rays == Hs * Ws else None,
+                         sink=_HostSink(N_rays, ray_batch["ray_o"].device) if on_gpu and STREAM_TO_HOST else None)
+    return acc.finish(Hs, Ws) if isinstance(acc, _HostSink) else _merge(acc, Hs, Ws)
 
 
 def shard_rows(Hs, world_size):

@@ -1058,6 +1058,19 @@ def test_render_single_image_vs_golden(dev, net, prec, golden):
             for k in ("rgb", "depth", "weights", "feats_out", "feats_out_3d"):
                 got = torch.cat(acc[lvl][k], dim=0).cpu().reshape(outs[0][lvl][k].shape)
                 assert torch.equal(got, outs[0][lvl][k]), "result depends on the chunks in flight (%d: %s %s)" % (n, lvl, k)
+    # outputs too large for the page-locked staging buffers take the copy-after-the-loop path: same tensors
+    keep = render_image.PINNED_KEEP_BYTES
+    render_image.PINNED_KEEP_BYTES = 1 << 16  # rgb / depth still staged per chunk, weights / feats_out / feats_out_3d not
+    try:
+        big = render_single_image(sampler, rb, _model(net), Projector(dev), 50, N_samples=16, inv_uniform=True,
+                                  N_importance=8, det=True, render_stride=1, featmaps=c["featmaps"].to(dev),
+                                  deep_semantics=c["deep_semantics"].to(dev), ret_alpha=True, single_net=True)
+    finally:
+        render_image.PINNED_KEEP_BYTES = keep
+    for lvl in ("outputs_coarse", "outputs_fine"):
+        assert list(big[lvl]) == list(outs[0][lvl]), "key order of the result changed"
+        for k in big[lvl]:
+            assert torch.equal(big[lvl][k], outs[0][lvl][k]), (lvl, k)
 
 
 def test_render_rays_stress_shape(dev, net, prec):
